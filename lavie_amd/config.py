@@ -1,0 +1,43 @@
+"""Static description of the denoiser, mirroring the constructor arguments the reference
+instantiates (`/root/reference/base/models/unet.py:102-141` through `from_pretrained_2d`,
+`unet.py:540-588`, with SD-1.4's `unet/config.json`: cross_attention_dim 768, 8 heads)."""
+from dataclasses import dataclass, field
+from typing import Tuple
+
+
+@dataclass(frozen=True)
+class UNetConfig:
+    sample_size: int = 64
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    heads: int = 8                       # `attention_head_dim=8` is the head COUNT (unet_blocks.py:289-291)
+    cross_attention_dim: int = 768
+    norm_groups: int = 32
+    norm_eps: float = 1e-5               # resnet / conv_norm_out GroupNorm; Transformer3DModel.norm uses 1e-6
+    rotary_dim: int = 32                 # RotaryEmbedding(32), unet.py:185
+    rel_buckets: int = 32                # RelativePositionBias(num_buckets=32, max_distance=32), attention.py:577
+    rel_max_distance: int = 32
+    attn_levels: Tuple[bool, ...] = field(default=(True, True, True, False))
+
+    @property
+    def time_embed_dim(self) -> int:
+        return self.block_out_channels[0] * 4
+
+    def validate(self) -> None:
+        n = len(self.block_out_channels)
+        if len(self.attn_levels) != n:
+            raise ValueError("attn_levels must have one entry per block_out_channels entry")
+        for c, a in zip(self.block_out_channels, self.attn_levels):
+            if c % 64 != 0:
+                raise ValueError(f"channel width {c} must be a multiple of 64 (K-tile of the MFMA kernels)")
+            if c % self.norm_groups != 0:
+                raise ValueError(f"channel width {c} not divisible by {self.norm_groups} groups")
+            if a and (c % self.heads != 0 or c // self.heads < self.rotary_dim or (c // self.heads) % 8 != 0):
+                raise ValueError(f"width {c}: head dim must be a multiple of 8 and >= rotary_dim")
+        if self.cross_attention_dim % 64 != 0:
+            raise ValueError("cross_attention_dim must be a multiple of 64")
+
+
+BASE_CONFIG = UNetConfig()

@@ -1,0 +1,36 @@
+"""Builds the reference UNet (under tests/refshim) with seeded synthetic weights.  TEST INFRASTRUCTURE."""
+import contextlib
+
+import torch
+
+import refimport
+from lavie_amd import spec, weights
+from lavie_amd.config import UNetConfig
+
+
+@contextlib.contextmanager
+def _no_init():
+    """Skips the default random init while the reference constructor runs (weights are overwritten)."""
+    names = ["kaiming_uniform_", "uniform_", "normal_", "zeros_", "ones_", "constant_", "xavier_uniform_", "trunc_normal_"]
+    saved = {n: getattr(torch.nn.init, n) for n in names}
+    for n in names:
+        setattr(torch.nn.init, n, lambda t, *a, **k: t)
+    try:
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(torch.nn.init, n, f)
+
+
+def reference_unet(cfg: UNetConfig, seed: int):
+    m = refimport.load()
+    with _no_init():
+        net = m.unet.UNet3DConditionModel(
+            sample_size=cfg.sample_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+            block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+            cross_attention_dim=cfg.cross_attention_dim, attention_head_dim=cfg.heads,
+            norm_num_groups=cfg.norm_groups, norm_eps=cfg.norm_eps)
+    sd = weights.synth_state_dict(spec.param_shapes(cfg), seed)
+    missing, unexpected = net.load_state_dict(sd, strict=True), None
+    net.eval()
+    return net, sd

@@ -1,0 +1,32 @@
+"""Loads the reference's base/models package under tests/refshim (TEST INFRASTRUCTURE).
+
+Only used in the build container: /root/reference does not exist on the GPU box, so
+every caller must skip when `available()` is False."""
+import importlib.util
+import os
+import sys
+
+REF = "/root/reference/base/models"
+_SHIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refshim")
+
+
+def available():
+    return os.path.isfile(os.path.join(REF, "unet.py"))
+
+
+def load():
+    """Returns the reference modules (resnet, attention, unet_blocks, unet) as a namespace."""
+    if "refmodels.unet" in sys.modules:
+        return sys.modules["refmodels"]
+    if _SHIM not in sys.path:
+        sys.path.insert(0, _SHIM)
+    pkg = importlib.util.module_from_spec(importlib.machinery.ModuleSpec("refmodels", None, is_package=True))
+    pkg.__path__ = [REF]
+    sys.modules["refmodels"] = pkg
+    for name in ("resnet", "attention", "unet_blocks", "unet"):
+        spec = importlib.util.spec_from_file_location(f"refmodels.{name}", os.path.join(REF, f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"refmodels.{name}"] = mod
+        spec.loader.exec_module(mod)
+        setattr(pkg, name, mod)
+    return pkg

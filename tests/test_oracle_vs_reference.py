@@ -1,0 +1,123 @@
+"""Pins oracle/ against the reference's own modules (build container only)."""
+import pytest
+import torch
+
+import refbuild
+import refimport
+from lavie_amd import spec
+from lavie_amd.config import UNetConfig
+from oracle import unet_fp32 as O
+
+pytestmark = pytest.mark.reference
+
+SMALL = UNetConfig(block_out_channels=(256, 512, 512, 512), cross_attention_dim=128)
+
+
+def rel_l2(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+def ocfg(cfg):
+    return O.UNetConfig(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+                        block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+                        heads=cfg.heads, cross_attention_dim=cfg.cross_attention_dim)
+
+
+@pytest.fixture(scope="module")
+def small():
+    torch.manual_seed(0)
+    net, sd = refbuild.reference_unet(SMALL, seed=3)
+    return net, sd
+
+
+def test_state_dict_keys_match_reference(small):
+    net, _ = small
+    ref = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert ref == spec.param_shapes(SMALL) == O.param_shapes(ocfg(SMALL))
+
+
+def test_base_spec_counts():
+    shapes = spec.param_shapes()
+    assert len(shapes) == 830                                   # SURVEY §3.2 [probe]
+    assert spec.param_count() == 909_124_116 + 15 * 16          # shared rotary freqs listed 16x in the state dict
+
+
+@pytest.mark.parametrize("t", [980, 500, 0])
+def test_whole_unet_small(small, t):
+    net, sd = small
+    g = torch.Generator().manual_seed(10 + t)
+    x = torch.randn(2, 4, 16, 8, 8, generator=g)
+    ctx = torch.randn(2, 77, SMALL.cross_attention_dim, generator=g)
+    with torch.no_grad():
+        ref = net(x, torch.tensor(t), encoder_hidden_states=ctx).sample
+        got = O.unet_forward(sd, x, t, ctx, ocfg(SMALL))
+    assert rel_l2(got, ref) < 1e-4
+
+
+def test_resnet_block_direct_import():
+    """T1: resnet.py imports standalone; 5-D GroupNorm domain and shortcut."""
+    m = refimport.load()
+    for cin, cout in ((64, 128), (64, 64)):
+        torch.manual_seed(cin + cout)
+        blk = m.resnet.ResnetBlock3D(in_channels=cin, out_channels=cout, temb_channels=256, groups=32, eps=1e-5).eval()
+        sd = {"r." + k: v for k, v in blk.state_dict().items()}
+        x = torch.randn(2, cin, 4, 8, 8) * torch.linspace(0.5, 2.0, 4).reshape(1, 1, 4, 1, 1)
+        temb = torch.randn(2, 256)
+        with torch.no_grad():
+            ref = blk(x, temb)
+            got = O.resnet_block(sd, "r.", x, temb, O.UNetConfig())
+        assert rel_l2(got, ref) < 1e-5
+
+
+def test_up_down_sample_direct_import():
+    m = refimport.load()
+    torch.manual_seed(1)
+    up = m.resnet.Upsample3D(64, use_conv=True, out_channels=64).eval()
+    dn = m.resnet.Downsample3D(64, use_conv=True, out_channels=64, padding=1, name="op").eval()
+    x = torch.randn(1, 64, 4, 8, 8)
+    with torch.no_grad():
+        assert rel_l2(O.upsample({"u." + k: v for k, v in up.state_dict().items()}, "u.", x), up(x)) < 1e-5
+        assert rel_l2(O.downsample({"d." + k: v for k, v in dn.state_dict().items()}, "d.", x), dn(x)) < 1e-5
+
+
+@pytest.mark.parametrize("c,frames", [(320, 16), (640, 16), (1280, 16), (320, 61)])
+def test_temporal_attention(c, frames):
+    m = refimport.load()
+    from rotary_embedding_torch import RotaryEmbedding
+    torch.manual_seed(c + frames)
+    att = m.attention.TemporalAttention(query_dim=c, heads=8, dim_head=c // 8, rotary_emb=RotaryEmbedding(32)).eval()
+    torch.nn.init.normal_(att.to_out[0].weight, std=0.02)
+    sd = {"a." + k: v for k, v in att.state_dict().items()}
+    x = torch.randn(64, frames, c)
+    with torch.no_grad():
+        ref = att(x)
+        got = O.temporal_attention(sd, "a.", x, O.UNetConfig())
+    assert rel_l2(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("n", [16, 61])
+def test_rel_pos_buckets(n):
+    m = refimport.load()
+    q = torch.arange(n)
+    rel = q.reshape(1, n) - q.reshape(n, 1)
+    ref = m.attention.RelativePositionBias._relative_position_bucket(rel, num_buckets=32, max_distance=32)
+    assert torch.equal(O.rel_pos_bucket_table(n, 32, 32), ref)
+    if n == 16:   # SURVEY §8 a15 row q=0 / col k=0
+        assert ref[0].tolist() == [0, 17, 18, 19, 20, 21, 22, 23, 24, 24, 25, 25, 26, 26, 27, 27]
+        assert ref[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 9, 10, 10, 11, 11]
+
+
+def test_transformer3d_block_order():
+    m = refimport.load()
+    from rotary_embedding_torch import RotaryEmbedding
+    torch.manual_seed(5)
+    tr = m.attention.Transformer3DModel(8, 40, in_channels=320, num_layers=1, cross_attention_dim=768,
+                                        norm_num_groups=32, rotary_emb=RotaryEmbedding(32)).eval()
+    torch.nn.init.normal_(tr.transformer_blocks[0].attn_temp.to_out[0].weight, std=0.02)
+    sd = {"t." + k: v for k, v in tr.state_dict().items()}
+    x = torch.randn(2, 320, 16, 8, 8) * torch.linspace(0.5, 2.0, 16).reshape(1, 1, 16, 1, 1)
+    ctx = torch.randn(2, 77, 768)
+    with torch.no_grad():
+        ref = tr(x, encoder_hidden_states=ctx, use_image_num=0).sample
+        got = O.transformer3d(sd, "t.", x, ctx, O.UNetConfig())
+    assert rel_l2(got, ref) < 1e-5
