@@ -1,0 +1,153 @@
+/* lavie_hip.h — C ABI of liblavie_hip.so: the MI355X (gfx950) implementation of the LaVie base
+ * text-to-video denoising path.
+ *
+ * The reference (rigelshysaj/LaVie) is pure PyTorch and has no plugin/FFI seam; its seam is the
+ * Python object protocol of `UNet3DConditionModel.forward` (base/models/unet.py:366-512) and the
+ * sub-module forwards below it.  Each entry point cites the reference code it replaces.  The
+ * Python facade in lavie_amd/ binds these symbols with ctypes (INTEGRATION.md shows the binding a
+ * reference maintainer would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in `_host`; `stream` is a hipStream_t
+ *    passed as void* (NULL = default stream); kernels are enqueued, never synchronised;
+ *  - activations are fp16, CHANNELS-LAST: a video tensor [b, c, f, h, w] of the reference is stored
+ *    as rows (b, f, y, x) of c contiguous halfs, which is also the reference's token layout
+ *    "(b f) (h w) c" (attention.py:373) — the NCFHW <-> channels-last conversion happens only in
+ *    lavie_unet_forward's first and last convolution;
+ *  - norm scales/biases and linear biases are fp32 device arrays; weights are fp16;
+ *  - the caller owns every buffer it passes; a lavie_unet_t owns its packed weights and workspace;
+ *  - return value 0 = ok, negative = error, message from lavie_last_error() (thread local);
+ *  - one host thread per process per GPU; no call may run concurrently on the same handle.
+ */
+#ifndef LAVIE_HIP_H
+#define LAVIE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAVIE_ABI_VERSION 1
+#define LAVIE_MAX_LEVELS 8
+
+const char* lavie_last_error(void);
+int lavie_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operators (the finer seam: SURVEY.md §8b "Sub-modules")
+ * ---------------------------------------------------------------------------------------------- */
+
+/* C[M,N] = A[M,K] W[N,K]^T (+ bias[N]) (+ bias2[m / rows_per_batch, N]) (+ R[M,N]).
+ * Replaces nn.Linear / 1x1 Conv2d: to_q/to_k/to_v/to_out (attention.py:95-104,154,177-178,202),
+ * proj_in/proj_out (attention.py:328,356,371,394), FeedForward.net.2 (attention.py:479).
+ * geglu != 0: W/bias hold the GEGLU projection in lavie_pack_geglu order and
+ * C[M, N/2] = h * gelu_erf(gate) (diffusers GEGLU; spec vsr/models/diffusers_attention.py:801-822).
+ * K %% 64 == 0, N %% 64 == 0 (N %% 128 for geglu); R may alias C. */
+int lavie_linear_f16(const void* A, int lda, const void* W, const float* bias, const float* bias2, int ldb2,
+                     int rows_per_batch, const void* R, int ldr, void* C, int ldc, int M, int N, int K, int geglu,
+                     void* stream);
+
+/* Per-frame 3x3 convolution, pad 1, on channels-last images; implicit GEMM.
+ * Replaces InflatedConv3d (resnet.py:13-21) as used by ResnetBlock3D.conv1/conv2 (resnet.py:183,200),
+ * Downsample3D (stride 2, resnet.py:102-110), Upsample3D (nearest x2 folded into the gather: `ups`=1,
+ * resnet.py:62-72), the skip concatenation torch.cat([h, skip]) (x2/C2 != 0, unet_blocks.py:538,630)
+ * and the fused 1x1 conv_shortcut (sc1/sc2 appended to K, resnet.py:175,203).
+ *   x1,x2 : [NI, Hi, Wi, C1|C2]          Wp : [Cout, 9*(C1+C2) + SC1 + SC2] (lavie_pack_conv3x3 order)
+ *   y     : [NI, Ho, Wo, Cout],  Ho = ups ? 2*Hi : (Hi + 2 - 3)/stride + 1
+ *   bias2 : per-video bias [NI/frames_per_video... ] see rows_per_batch; R: residual [M, Cout].
+ * All channel counts are multiples of 64. */
+int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void* sc1, int SC1, const void* sc2, int SC2,
+                      const void* Wp, const float* bias, const float* bias2, int ldb2, int rows_per_batch, const void* R,
+                      void* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const void* zero_page,
+                      void* stream);
+
+/* [Cout, Cin, 3, 3] (PyTorch) -> rows of `ld_out` halfs: out[co, col0 + (ky*3+kx)*Cin + ci]. */
+int lavie_pack_conv3x3_f16(const void* w, void* out, int Cout, int Cin, int ld_out, int col0, void* stream);
+/* GEGLU projection [2*inner, K] (+ bias) -> 16-row value/gate interleave expected by lavie_linear_f16(geglu=1). */
+int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float* bias_out, int N, int K, void* stream);
+
+/* GroupNorm (+ optional SiLU) over channels-last rows; the "batch" is whatever shares statistics:
+ *   video domain  (resnet.py:180,191; unet.py:504): NB = b,   P = f*h*w   rows per batch
+ *   frame domain  (attention.py:324,369)          : NB = b*f, P = h*w
+ * Input may be the virtual concat [x1 | x2].  stats_ws: NB*groups*2 floats of scratch. */
+int lavie_group_norm_f16(const void* x1, int C1, const void* x2, int C2, int NB, int P, int groups, const float* gamma,
+                         const float* beta, float eps, int silu, float* stats_ws, void* y, void* stream);
+
+/* nn.LayerNorm(C) over rows (attention.py:442,459,474,480). */
+int lavie_layer_norm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
+                         void* stream);
+
+/* softmax(scale q k^T) v with heads packed along channels; replaces CrossAttention._attention
+ * (attention.py:209-239) and reshape_heads_to_batch_dim / reshape_batch_dim_to_heads (112-124).
+ * q: [NB*Lq, ldq], k/v: [(NB/kv_batch_div)*Lk, ld], o: [NB*Lq, ldo]; head h at columns h*dh. */
+int lavie_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int NB,
+                        int Lq, int Lk, int heads, int dh, int kv_batch_div, float scale, void* stream);
+
+/* TemporalAttention._attention (attention.py:634-667) on tokens ordered (b, f, pixel):
+ * qkv [B*F*D, ld] = q | k | v, o [B*F*D, ldo]; bias [heads, F, F] fp32 (query, key);
+ * rot_cos/rot_sin [F, rot_dim/2] fp32. */
+int lavie_temporal_attention_f16(const void* qkv, int ld, void* o, int ldo, int B, int F, int D, int heads, int dh,
+                                 const float* bias, const float* rot_cos, const float* rot_sin, int rot_dim, float scale,
+                                 void* stream);
+
+/* T5-style relative position buckets of RelativePositionBias (attention.py:681-699), HOST function:
+ * out_host[i*F + j] = bucket(query i, key j). */
+int lavie_relpos_buckets(int F, int num_buckets, int max_distance, int* out_host);
+
+/* Classifier-free guidance + DDPM ancestral step, fused (pipeline_videogen.py:679-683 and
+ * diffusers DDPMScheduler.step): eps2 = [uncond | cond] fp16 (n each), x fp32 (updated in place),
+ * noise fp32 (may be NULL iff sigma == 0), model_in2 = fp16 [x' | x'] for the next UNet call. */
+int lavie_cfg_ddpm_step(const void* eps2, float* x, const float* noise, void* model_in2, long long n, float guidance,
+                        float k_x, float k_eps, float c_x0, float c_xt, float sigma, void* stream);
+int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole denoiser: UNet3DConditionModel.forward (unet.py:366-512)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lavie_unet_s* lavie_unet_t;
+
+typedef struct lavie_unet_config {
+    int in_channels, out_channels;
+    int num_levels;
+    int block_out_channels[LAVIE_MAX_LEVELS];
+    int attn_levels[LAVIE_MAX_LEVELS];      /* 1: CrossAttn{Down,Up}Block3D, 0: {Down,Up}Block3D */
+    int layers_per_block;
+    int heads;
+    int cross_attention_dim;
+    int norm_groups;
+    float norm_eps;
+    int rotary_dim;
+    int rel_buckets, rel_max_distance;
+} lavie_unet_config;
+
+int lavie_unet_create(const lavie_unet_config* cfg, lavie_unet_t* out);
+int lavie_unet_destroy(lavie_unet_t h);
+/* Number of state-dict entries the model expects and the i-th name/numel (reference key names,
+ * unet.py:142-295): lets a binder enumerate the checkpoint contract without Python. */
+int lavie_unet_num_params(lavie_unet_t h);
+int lavie_unet_param_info(lavie_unet_t h, int i, const char** name, long long* numel);
+/* Hand over one fp16 state-dict tensor (borrowed until lavie_unet_finalize returns and the stream drains). */
+int lavie_unet_set_param(lavie_unet_t h, const char* name, const void* data_f16, long long numel);
+/* Repack all weights into the engine's own arena (fused QKV, [Cout][tap][Cin] convs, GEGLU order, fp32 biases). */
+int lavie_unet_finalize(lavie_unet_t h, void* stream);
+/* Size the activation workspace for inputs up to [B, *, F, H, W] (allocates; not stream-ordered). */
+int lavie_unet_prepare(lavie_unet_t h, int B, int F, int H, int W, int ctx_len);
+long long lavie_unet_weight_bytes(lavie_unet_t h);
+long long lavie_unet_workspace_bytes(lavie_unet_t h);
+/* sample [B, Cin, F, H, W] fp16 (NCFHW, as the reference passes it), timesteps [B] fp32,
+ * ctx [B, ctx_len, cross_attention_dim] fp16  ->  out [B, Cout, F, H, W] fp16. */
+int lavie_unet_forward(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx, void* out, int B,
+                       int F, int H, int W, int ctx_len, void* stream);
+
+/* Finer engine seams for parity tests (same packed weights as the whole model):
+ * ResnetBlock3D.forward (resnet.py:177-207) and Transformer3DModel.forward (attention.py:358-407)
+ * of the block whose state-dict prefix is `prefix` (e.g. "down_blocks.0.resnets.0").
+ * x1/x2/y channels-last; temb [B, time_embed_dim] fp32 (the output of time_embedding, pre-SiLU). */
+int lavie_unet_resnet_forward(lavie_unet_t h, const char* prefix, const void* x1, int C1, const void* x2, int C2,
+                              const float* temb, void* y, int B, int F, int H, int W, void* stream);
+int lavie_unet_transformer_forward(lavie_unet_t h, const char* prefix, void* x_inout, const void* ctx, int B, int F, int H,
+                                   int W, int ctx_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAVIE_HIP_H */

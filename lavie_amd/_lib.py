@@ -1,0 +1,91 @@
+"""ctypes binding of liblavie_hip.so (C ABI: include/lavie_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C lavie_amd/csrc`.  There is no
+fallback: if the shared object is missing or a call fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblavie_hip.so")
+ABI_VERSION = 1
+MAX_LEVELS = 8
+
+c_void_p, c_int, c_float, c_ll, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_char_p
+c_float_p = C.c_void_p      # fp32 device pointers are passed as raw addresses
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [
+        ("in_channels", c_int), ("out_channels", c_int), ("num_levels", c_int),
+        ("block_out_channels", c_int * MAX_LEVELS), ("attn_levels", c_int * MAX_LEVELS),
+        ("layers_per_block", c_int), ("heads", c_int), ("cross_attention_dim", c_int), ("norm_groups", c_int),
+        ("norm_eps", c_float), ("rotary_dim", c_int), ("rel_buckets", c_int), ("rel_max_distance", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/lavie_hip.h
+SIGNATURES = {
+    "lavie_last_error": (c_char_p, []),
+    "lavie_abi_version": (c_int, []),
+    "lavie_linear_f16": (c_int, [c_void_p, c_int, c_void_p, c_float_p, c_float_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lavie_conv3x3_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_float_p,
+                                   c_float_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p]),
+    "lavie_pack_conv3x3_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "lavie_pack_geglu_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_int, c_void_p]),
+    "lavie_group_norm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float_p, c_float_p, c_float,
+                                      c_int, c_float_p, c_void_p, c_void_p]),
+    "lavie_layer_norm_f16": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "lavie_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_float, c_void_p]),
+    "lavie_temporal_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float_p,
+                                              c_float_p, c_float_p, c_int, c_float, c_void_p]),
+    "lavie_relpos_buckets": (c_int, [c_int, c_int, c_int, C.POINTER(c_int)]),
+    "lavie_cfg_ddpm_step": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
+                                     c_float, c_float, c_void_p]),
+    "lavie_latents_to_model_input": (c_int, [c_float_p, c_void_p, c_ll, c_void_p]),
+    "lavie_unet_create": (c_int, [C.POINTER(UNetConfigC), C.POINTER(c_void_p)]),
+    "lavie_unet_destroy": (c_int, [c_void_p]),
+    "lavie_unet_num_params": (c_int, [c_void_p]),
+    "lavie_unet_param_info": (c_int, [c_void_p, c_int, C.POINTER(c_char_p), C.POINTER(c_ll)]),
+    "lavie_unet_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_ll]),
+    "lavie_unet_finalize": (c_int, [c_void_p, c_void_p]),
+    "lavie_unet_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "lavie_unet_weight_bytes": (c_ll, [c_void_p]),
+    "lavie_unet_workspace_bytes": (c_ll, [c_void_p]),
+    "lavie_unet_forward": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p]),
+    "lavie_unet_resnet_forward": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_void_p, c_int, c_float_p, c_void_p, c_int,
+                                           c_int, c_int, c_int, c_void_p]),
+    "lavie_unet_transformer_forward": (c_int, [c_void_p, c_char_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the bound CDLL; raises RuntimeError if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C lavie_amd/csrc).  lavie_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lavie_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"liblavie_hip.so ABI {lib.lavie_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "lavie call"):
+    if rc != 0:
+        msg = load().lavie_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,208 @@
+// extern "C" surface of liblavie_hip.so (declared in include/lavie_hip.h).
+#include <string.h>
+
+#include <new>
+
+#include "engine.h"
+
+using namespace lavie;
+
+struct lavie_unet_s {
+    UNet net;
+    explicit lavie_unet_s(const lavie_unet_config& c) : net(c) {}
+};
+
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+static inline const half_t* H(const void* p) { return (const half_t*)p; }
+static inline half_t* H(void* p) { return (half_t*)p; }
+
+extern "C" {
+
+const char* lavie_last_error(void) { return get_error(); }
+int lavie_abi_version(void) { return LAVIE_ABI_VERSION; }
+
+int lavie_linear_f16(const void* A, int lda, const void* W, const float* bias, const float* bias2, int ldb2,
+                     int rows_per_batch, const void* R, int ldr, void* C, int ldc, int M, int N, int K, int geglu,
+                     void* stream) {
+    LAVIE_CHECK(A && W && C, "linear: null tensor");
+    LAVIE_CHECK(K % IGEMM_BK == 0, "linear: K=%d must be a multiple of %d", K, IGEMM_BK);
+    LAVIE_CHECK(!bias2 || rows_per_batch > 0, "linear: bias2 needs rows_per_batch > 0");
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = H(A); p.lda = lda; p.W = H(W); p.ldw = K; p.C = H(C); p.ldc = ldc; p.bias = bias;
+    p.bias2 = bias2; p.ldb2 = ldb2; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.R = H(R); p.ldr = ldr; p.M = M; p.N = N; p.nk = K / IGEMM_BK;
+    return launch_igemm(p, false, geglu ? EPI_GEGLU : EPI_LINEAR, S(stream));
+}
+
+int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void* sc1, int SC1, const void* sc2, int SC2,
+                      const void* Wp, const float* bias, const float* bias2, int ldb2, int rows_per_batch, const void* R,
+                      void* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const void* zero_page,
+                      void* stream) {
+    LAVIE_CHECK(x1 && Wp && y && zero_page, "conv3x3: null tensor");
+    LAVIE_CHECK((stride == 1 || stride == 2) && (ups == 0 || ups == 1) && !(ups && stride != 1), "conv3x3: stride=%d ups=%d", stride, ups);
+    LAVIE_CHECK(C1 > 0 && C1 % IGEMM_BK == 0 && C2 % IGEMM_BK == 0 && SC1 % IGEMM_BK == 0 && SC2 % IGEMM_BK == 0,
+                "conv3x3: channel counts must be multiples of %d", IGEMM_BK);
+    LAVIE_CHECK((!SC1 && !SC2) || (stride == 1 && !ups), "conv3x3: fused shortcut needs stride 1, no upsample");
+    LAVIE_CHECK(!bias2 || rows_per_batch > 0, "conv3x3: bias2 needs rows_per_batch > 0");
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.W = H(Wp); p.C = H(y); p.ldc = Cout; p.bias = bias; p.bias2 = bias2; p.ldb2 = ldb2;
+    p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.R = H(R); p.ldr = Cout;
+    p.Hi = Hi; p.Wi = Wi; p.stride = stride; p.ups = ups;
+    p.Ho = ups ? Hi * 2 : (Hi - 1) / stride + 1;
+    p.Wo = ups ? Wi * 2 : (Wi - 1) / stride + 1;
+    p.M = NI * p.Ho * p.Wo; p.N = Cout; p.zero = H(zero_page);
+    int ns = 0, nk = 0;
+    const half_t* src[2] = {H(x1), H(x2)};
+    const int srcC[2] = {C1, x2 ? C2 : 0};
+    for (int tap = 0; tap < 9; ++tap)
+        for (int i = 0; i < 2; ++i) {
+            if (!srcC[i]) continue;
+            IgemmSeg& sg = p.seg[ns++];
+            sg.src = src[i]; sg.C = srcC[i]; sg.c0 = 0; sg.nchunks = srcC[i] / IGEMM_BK; sg.dy = tap / 3 - 1; sg.dx = tap % 3 - 1;
+            nk += sg.nchunks;
+        }
+    const half_t* sc[2] = {H(sc1), H(sc2)};
+    const int scC[2] = {sc1 ? SC1 : 0, sc2 ? SC2 : 0};
+    for (int i = 0; i < 2; ++i) {
+        if (!scC[i]) continue;
+        IgemmSeg& sg = p.seg[ns++];
+        sg.src = sc[i]; sg.C = scC[i]; sg.c0 = 0; sg.nchunks = scC[i] / IGEMM_BK; sg.dy = 0; sg.dx = 0;
+        nk += sg.nchunks;
+    }
+    p.nseg = ns; p.nk = nk; p.ldw = nk * IGEMM_BK;
+    return launch_igemm(p, true, EPI_LINEAR, S(stream));
+}
+
+int lavie_pack_conv3x3_f16(const void* w, void* out, int Cout, int Cin, int ld_out, int col0, void* stream) {
+    LAVIE_CHECK(w && out && ld_out >= col0 + 9 * Cin, "pack_conv3x3: bad arguments");
+    return launch_pack_conv3x3(H(w), H(out), Cout, Cin, ld_out, col0, S(stream));
+}
+
+int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float* bias_out, int N, int K, void* stream) {
+    LAVIE_CHECK(w && w_out, "pack_geglu: null tensor");
+    int rc = launch_pack_geglu_rows(H(w), H(w_out), N, K, S(stream));
+    if (rc == 0 && bias_f16 && bias_out) rc = launch_pack_geglu_bias(H(bias_f16), bias_out, N, S(stream));
+    return rc;
+}
+
+int lavie_group_norm_f16(const void* x1, int C1, const void* x2, int C2, int NB, int P, int groups, const float* gamma,
+                         const float* beta, float eps, int silu, float* stats_ws, void* y, void* stream) {
+    LAVIE_CHECK(x1 && gamma && beta && stats_ws && y, "group_norm: null tensor");
+    LAVIE_CHECK(NB > 0 && P > 0 && groups > 0, "group_norm: empty problem");
+    if (!x2) C2 = 0;
+    LAVIE_HIP(hipMemsetAsync(stats_ws, 0, (size_t)NB * groups * 2 * sizeof(float), S(stream)));
+    int rc = launch_gn_stats(H(x1), C1, H(x2), C2, NB, P, groups, stats_ws, S(stream));
+    if (rc) return rc;
+    return launch_gn_apply(H(x1), C1, H(x2), C2, NB, P, groups, stats_ws, gamma, beta, eps, silu != 0, H(y), S(stream));
+}
+
+int lavie_layer_norm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
+                         void* stream) {
+    LAVIE_CHECK(x && gamma && beta && y && rows > 0, "layer_norm: bad arguments");
+    return launch_layernorm(H(x), gamma, beta, H(y), rows, C, eps, S(stream));
+}
+
+int lavie_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int NB,
+                        int Lq, int Lk, int heads, int dh, int kv_batch_div, float scale, void* stream) {
+    LAVIE_CHECK(q && k && v && o, "attention: null tensor");
+    AttnParams a;
+    a.q = H(q); a.ldq = ldq; a.k = H(k); a.ldk = ldk; a.v = H(v); a.ldv = ldv; a.o = H(o); a.ldo = ldo;
+    a.NBq = NB; a.Lq = Lq; a.Lk = Lk; a.heads = heads; a.dh = dh; a.kv_batch_div = kv_batch_div; a.scale = scale;
+    return launch_attention(a, S(stream));
+}
+
+int lavie_temporal_attention_f16(const void* qkv, int ld, void* o, int ldo, int B, int F, int D, int heads, int dh,
+                                 const float* bias, const float* rot_cos, const float* rot_sin, int rot_dim, float scale,
+                                 void* stream) {
+    LAVIE_CHECK(qkv && o && bias && rot_cos && rot_sin, "temporal attention: null tensor");
+    LAVIE_CHECK(F <= 16, "temporal attention: F=%d > 16 not enabled in this build", F);
+    TemporalParams t;
+    t.qkv = H(qkv); t.ld = ld; t.o = H(o); t.ldo = ldo; t.B = B; t.F = F; t.D = D; t.heads = heads; t.dh = dh;
+    t.bias = bias; t.rot_cos = rot_cos; t.rot_sin = rot_sin; t.rot_dim = rot_dim; t.scale = scale;
+    return launch_temporal_attention(t, S(stream));
+}
+
+int lavie_relpos_buckets(int F, int num_buckets, int max_distance, int* out_host) {
+    LAVIE_CHECK(F > 0 && num_buckets >= 4 && max_distance > num_buckets / 4 && out_host, "relpos_buckets: bad arguments");
+    relpos_bucket_table(F, num_buckets, max_distance, out_host);
+    return 0;
+}
+
+int lavie_cfg_ddpm_step(const void* eps2, float* x, const float* noise, void* model_in2, long long n, float guidance,
+                        float k_x, float k_eps, float c_x0, float c_xt, float sigma, void* stream) {
+    LAVIE_CHECK(eps2 && x && model_in2 && n > 0, "cfg_ddpm_step: bad arguments");
+    return launch_cfg_ddpm_step(H(eps2), x, noise, H(model_in2), n, guidance, k_x, k_eps, c_x0, c_xt, sigma, S(stream));
+}
+
+int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, void* stream) {
+    LAVIE_CHECK(x && model_in2 && n > 0, "latents_to_model_input: bad arguments");
+    return launch_f32_to_f16_dup2(x, H(model_in2), n, S(stream));
+}
+
+int lavie_unet_create(const lavie_unet_config* cfg, lavie_unet_t* out) {
+    LAVIE_CHECK(cfg && out, "unet_create: null argument");
+    LAVIE_CHECK(cfg->num_levels >= 1 && cfg->num_levels <= LAVIE_MAX_LEVELS, "unet_create: num_levels=%d", cfg->num_levels);
+    lavie_unet_s* h = new (std::nothrow) lavie_unet_s(*cfg);
+    LAVIE_CHECK(h != nullptr, "unet_create: out of host memory");
+    if (int rc = h->net.validate_config()) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+int lavie_unet_destroy(lavie_unet_t h) {
+    delete h;
+    return 0;
+}
+
+int lavie_unet_num_params(lavie_unet_t h) { return h ? (int)h->net.params().size() : -1; }
+
+int lavie_unet_param_info(lavie_unet_t h, int i, const char** name, long long* numel) {
+    LAVIE_CHECK(h && i >= 0 && i < (int)h->net.params().size(), "param_info: index %d out of range", i);
+    if (name) *name = h->net.params()[i].name.c_str();
+    if (numel) *numel = h->net.params()[i].numel;
+    return 0;
+}
+
+int lavie_unet_set_param(lavie_unet_t h, const char* name, const void* data_f16, long long numel) {
+    LAVIE_CHECK(h && name, "set_param: null argument");
+    return h->net.set_param(name, data_f16, numel);
+}
+
+int lavie_unet_finalize(lavie_unet_t h, void* stream) {
+    LAVIE_CHECK(h, "finalize: null handle");
+    return h->net.finalize(S(stream));
+}
+
+int lavie_unet_prepare(lavie_unet_t h, int B, int F, int Hh, int W, int ctx_len) {
+    LAVIE_CHECK(h, "prepare: null handle");
+    return h->net.prepare(B, F, Hh, W, ctx_len);
+}
+
+long long lavie_unet_weight_bytes(lavie_unet_t h) { return h ? h->net.weight_bytes() : -1; }
+long long lavie_unet_workspace_bytes(lavie_unet_t h) { return h ? h->net.workspace_bytes() : -1; }
+
+int lavie_unet_forward(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx, void* out, int B,
+                       int F, int Hh, int W, int ctx_len, void* stream) {
+    LAVIE_CHECK(h, "forward: null handle");
+    return h->net.forward(H(sample), timesteps, H(ctx), H(out), B, F, Hh, W, ctx_len, S(stream));
+}
+
+int lavie_unet_resnet_forward(lavie_unet_t h, const char* prefix, const void* x1, int C1, const void* x2, int C2,
+                              const float* temb, void* y, int B, int F, int Hh, int W, void* stream) {
+    LAVIE_CHECK(h && prefix && x1 && temb && y, "resnet_forward: null argument");
+    return h->net.resnet_forward(prefix, H(x1), C1, H(x2), C2, temb, H(y), B, F, Hh, W, S(stream));
+}
+
+int lavie_unet_transformer_forward(lavie_unet_t h, const char* prefix, void* x_inout, const void* ctx, int B, int F, int Hh,
+                                   int W, int ctx_len, void* stream) {
+    LAVIE_CHECK(h && prefix && x_inout && ctx, "transformer_forward: null argument");
+    return h->net.transformer_forward(prefix, H(x_inout), H(ctx), B, F, Hh, W, ctx_len, S(stream));
+}
+
+}  // extern "C"

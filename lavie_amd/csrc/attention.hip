@@ -1,0 +1,254 @@
+// Fused attention core for spatial self-attention and text cross-attention:
+//   O = softmax(scale * Q K^T) V   per (frame, head), never materialising the [Lq, Lk] scores.
+// Replaces `CrossAttention._attention` (attention.py:209-239: baddbmm / softmax / bmm) together with
+// the head split / merge reshapes (attention.py:112-124): heads stay packed along the channel axis
+// of the projection outputs, the kernel indexes them in place.
+//
+// Structure (per workgroup = 4 waves, one (q-block, head, frame)):
+//  * each wave owns QT x 16 query rows; K/V tiles of 64 keys are staged through LDS for all waves
+//    (register-staged: next tile's global loads are issued before the current tile's MFMAs and
+//    written to LDS after them — T14 of the guide);
+//  * S^T = K Q^T with v_mfma_f32_16x16x32_f16 (keys on the accumulator rows, the query on the lane),
+//    so the row softmax is 16 in-register values + two cross-lane steps, and P^T is ALREADY the B
+//    operand of the second product (guide §3 "accumulator tile as the next MFMA's operand");
+//  * O^T = V^T P^T: V^T fragments come from the row-major V tile with ds_read_b64_tr_b16
+//    (hardware transpose, T10); rows are padded by 32 B so both the K ds_read_b128 and the V
+//    transposed reads are bank-conflict-free (stride = 32 B x odd);
+//  * online softmax in fp32 with exp2, head dims that are not MFMA multiples (40, 80) are zero
+//    padded in LDS only — HBM traffic stays at the true head width.
+#include "common.h"
+#include "ops.h"
+
+namespace lavie {
+
+constexpr int ATT_KEYS = 64;   // keys per tile
+
+template <int DHP>
+struct AttTile {
+    static constexpr int STRIDE = DHP * 2 + 32;          // bytes per key row in LDS
+    static constexpr int TILE_BYTES = ATT_KEYS * STRIDE; // one of K / V
+    static constexpr int LDS_BYTES = 2 * TILE_BYTES;
+    static constexpr int KS = DHP / 32;                  // k-steps of the QK^T contraction
+    static constexpr int DT = DHP / 16;                  // 16-wide output dim tiles (upper bound)
+    static constexpr int MAXPIECE = (ATT_KEYS * (DHP / 8) + 255) / 256;
+};
+
+template <int DHP, int QT>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+    using T = AttTile<DHP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + T::TILE_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4;       // 16-lane group
+    const int li = lane & 15;
+    const int head = blockIdx.y;
+    const int qb = blockIdx.z;
+    const int kvb = qb / p.kv_batch_div;
+    const int dh = p.dh;
+    const int nch = dh >> 3;       // 16-byte chunks per key row that exist in HBM
+    const int q0 = blockIdx.x * (4 * QT * 16) + wave * (QT * 16);
+
+    // zero the padding columns once (chunks nch .. DHP/8 + 1): staging never writes them
+    for (int i = tid; i < ATT_KEYS * (T::STRIDE / 16 - nch); i += 256) {
+        const int key = i / (T::STRIDE / 16 - nch), c = nch + i % (T::STRIDE / 16 - nch);
+        *reinterpret_cast<f32x4*>(sK + key * T::STRIDE + c * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sV + key * T::STRIDE + c * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- Q fragments (B operand): lane holds Q[q = li][dims 32 ks + 8 g .. +7]
+    half8_t qf[QT][T::KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int q = q0 + qt * 16 + li;
+        q = q < p.Lq ? q : p.Lq - 1;
+        const half_t* qrow = p.q + ((size_t)qb * p.Lq + q) * p.ldq + head * dh;
+#pragma unroll
+        for (int ks = 0; ks < T::KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            if (d < dh) qf[qt][ks] = *reinterpret_cast<const half8_t*>(qrow + d);
+            else qf[qt][ks] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    const half_t* kbase = p.k + (size_t)kvb * p.Lk * p.ldk + head * dh;
+    const half_t* vbase = p.v + (size_t)kvb * p.Lk * p.ldv + head * dh;
+    const int npiece = ATT_KEYS * nch;
+    half8_t rk[T::MAXPIECE], rv[T::MAXPIECE];
+
+    auto load_tile = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < T::MAXPIECE; ++i) {
+            const int pc = tid + i * 256;
+            if (pc < npiece) {
+                const int key = pc / nch, c = pc - key * nch;
+                const int kg = key0 + key;
+                if (kg < p.Lk) {
+                    rk[i] = *reinterpret_cast<const half8_t*>(kbase + (size_t)kg * p.ldk + c * 8);
+                    rv[i] = *reinterpret_cast<const half8_t*>(vbase + (size_t)kg * p.ldv + c * 8);
+                } else {
+                    rk[i] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                    rv[i] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < T::MAXPIECE; ++i) {
+            const int pc = tid + i * 256;
+            if (pc < npiece) {
+                const int key = pc / nch, c = pc - key * nch;
+                *reinterpret_cast<half8_t*>(sK + key * T::STRIDE + c * 16) = rk[i];
+                *reinterpret_cast<half8_t*>(sV + key * T::STRIDE + c * 16) = rv[i];
+            }
+        }
+    };
+
+    f32x4 o[T::DT][QT];
+#pragma unroll
+    for (int dt = 0; dt < T::DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+
+    const float sl2 = p.scale * 1.4426950408889634f;   // scores in log2 units
+    const int ntile = cdiv(p.Lk, ATT_KEYS);
+    const int ndt = (dh + 15) >> 4;
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) load_tile((t + 1) * ATT_KEYS);
+
+        // ---- S^T[key, q] = K Q^T
+        f32x4 s[4][QT];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < T::KS; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const half8_t kf = *reinterpret_cast<const half8_t*>(sK + (kt * 16 + li) * T::STRIDE + (ks * 4 + g) * 16);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax, per query column (lane li of each 16-lane group)
+        const int kleft = p.Lk - t * ATT_KEYS;     // valid keys in this tile (may exceed 64)
+        half8_t pb[2][QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[kt][qt][r] * sl2;
+                    if (kt * 16 + g * 4 + r >= kleft) v = -INFINITY;
+                    s[kt][qt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);       // finite: every tile holds >= 1 valid key
+            const float alpha = exp2f(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(s[kt][qt][r] - m_new);
+                    psum += e;
+                    pb[kt >> 1][qt][(kt & 1) * 4 + r] = (half_t)e;
+                }
+            l_run[qt] = l_run[qt] * alpha + psum;            // per-lane partial; reduced over g at the end
+#pragma unroll
+            for (int dt = 0; dt < T::DT; ++dt) o[dt][qt] *= alpha;
+        }
+
+        // ---- O^T[dim, q] += V^T P^T  (V^T fragments by hardware-transposed LDS reads)
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int dt = 0; dt < T::DT; ++dt) {
+                if (dt < ndt) {
+                    const char* va = sV + (kt2 * 32 + g * 4 + (li >> 2)) * T::STRIDE + (dt * 16 + (li & 3) * 4) * 2;
+                    const fp16x4_raw lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va));
+                    const fp16x4_raw hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va + 16 * T::STRIDE));
+                    half8_t vf;
+                    __builtin_memcpy(&vf, &lo, 8);
+                    __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[kt2][qt], o[dt][qt], 0, 0, 0);
+                }
+            }
+        }
+
+        __syncthreads();                       // everyone is done reading tile t
+        if (t + 1 < ntile) store_tile();
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds dims dt*16 + 4g .. +3 of query li
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + qt * 16 + li;
+        if (q < p.Lq) {
+            half_t* orow = p.o + ((size_t)qb * p.Lq + q) * p.ldo + head * dh;
+#pragma unroll
+            for (int dt = 0; dt < T::DT; ++dt) {
+                const int d = dt * 16 + g * 4;
+                if (d < dh) {
+                    const f32x4 v = o[dt][qt];
+                    half4_t h = {(half_t)(v[0] * inv), (half_t)(v[1] * inv), (half_t)(v[2] * inv), (half_t)(v[3] * inv)};
+                    *reinterpret_cast<half4_t*>(orow + d) = h;
+                }
+            }
+        }
+    }
+}
+
+template <int DHP, int QT>
+static int launch_att(const AttnParams& p, hipStream_t stream) {
+    using T = AttTile<DHP>;
+    auto kern = attention_kernel<DHP, QT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.Lq, 4 * QT * 16), p.heads, p.NBq);
+    hipLaunchKernelGGL(kern, grid, dim3(256), T::LDS_BYTES, stream, p);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attention(const AttnParams& p, hipStream_t stream) {
+    LAVIE_CHECK(p.dh % 8 == 0 && p.dh >= 8 && p.dh <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", p.dh);
+    LAVIE_CHECK(p.Lq > 0 && p.Lk > 0 && p.NBq > 0 && p.heads > 0 && p.kv_batch_div > 0, "attention: empty problem");
+    LAVIE_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-B alignment");
+    const bool big = p.Lq > 64 * 3;     // >= 2 full 128-row blocks: use 32 rows per wave
+    if (p.dh <= 64) return big ? launch_att<64, 2>(p, stream) : launch_att<64, 1>(p, stream);
+    if (p.dh <= 96) return big ? launch_att<96, 2>(p, stream) : launch_att<96, 1>(p, stream);
+    return big ? launch_att<160, 2>(p, stream) : launch_att<160, 1>(p, stream);
+}
+
+}  // namespace lavie

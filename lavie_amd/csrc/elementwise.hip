@@ -1,0 +1,378 @@
+// Small kernels around the contraction core: time embedding, the two 4-channel convolutions at the
+// NCFHW boundary, the CFG + DDPM update, and the one-off weight repacking.
+#include <math.h>
+
+#include "common.h"
+#include "ops.h"
+
+namespace lavie {
+
+// ------------------------------------------------------------------ time embedding
+// Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) (unet.py:153,428): [cos(t w_k) | sin(t w_k)].
+__global__ void timestep_sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
+    const int half_dim = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half_dim) return;
+    const int b = i / half_dim, k = i - b * half_dim;
+    const float w = expf(-logf(10000.0f) * (float)k / (float)half_dim);
+    const float a = t[b] * w;
+    out[(size_t)b * dim + k] = cosf(a);
+    out[(size_t)b * dim + half_dim + k] = sinf(a);
+}
+
+int launch_timestep_sinusoid(const float* t, float* out, int B, int dim, hipStream_t stream) {
+    const int n = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, t, out, B, dim);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// Batched GEMV for the [B <= 8, K] time-embedding vectors: one wave per output feature.
+// Serves TimestepEmbedding (unet.py:434) and all ResnetBlock3D.time_emb_proj at once (resnet.py:186).
+constexpr int GEMV_MAXB = 8;
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ in, const half_t* __restrict__ W,
+                                                  const float* __restrict__ bias, float* __restrict__ out, int B, int N,
+                                                  int K, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[GEMV_MAXB];
+#pragma unroll
+    for (int b = 0; b < GEMV_MAXB; ++b) acc[b] = 0.f;
+    const half_t* wr = W + (size_t)n * K;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        const half8_t w = *reinterpret_cast<const half8_t*>(wr + k);
+#pragma unroll
+        for (int b = 0; b < GEMV_MAXB; ++b) {
+            if (b < B) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = in[(size_t)b * K + k + j];
+                    if (act_in) x = silu_f(x);
+                    acc[b] += x * (float)w[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < GEMV_MAXB; ++b) {
+        if (b < B) {
+            float v = wave_sum(acc[b]);
+            if (lane == 0) {
+                v += bias ? bias[n] : 0.f;
+                if (act_out) v = silu_f(v);
+                out[(size_t)b * N + n] = v;
+            }
+        }
+    }
+}
+
+int launch_gemv(const float* in, const half_t* W, const float* bias, float* out, int B, int N, int K, int act_in,
+                int act_out, hipStream_t stream) {
+    LAVIE_CHECK(B >= 1 && B <= GEMV_MAXB && K % 8 == 0, "gemv: unsupported B=%d K=%d", B, K);
+    hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, stream, in, W, bias, out, B, N, K, act_in, act_out);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ conv_in (unet.py:150,454)
+// Reads the caller's NCFHW latent, writes channels-last activations.  K = 9*Cin is tiny (36), so a
+// direct kernel: one thread per (pixel, 8 output channels), weights in LDS as [tap*Cin + ci][Cout].
+__global__ __launch_bounds__(256) void conv_in_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wp,
+                                                     const float* __restrict__ bias, half_t* __restrict__ y, int B,
+                                                     int Cin, int F, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sw = reinterpret_cast<half_t*>(smem);
+    const int kk = 9 * Cin;
+    for (int i = threadIdx.x * 8; i < kk * Cout; i += 256 * 8)
+        *reinterpret_cast<half8_t*>(sw + i) = *reinterpret_cast<const half8_t*>(wp + i);
+    __syncthreads();
+    const int ng = Cout >> 3;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long M = (long)B * F * H * W;
+    if (idx >= M * ng) return;
+    const long m = idx / ng;
+    const int g = (int)(idx - m * ng);
+    const int xw = (int)(m % W);
+    const int yh = (int)((m / W) % H);
+    const int f = (int)((m / ((long)W * H)) % F);
+    const int b = (int)(m / ((long)W * H * F));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yh + ky - 1;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = xw + kx - 1;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float v = (float)x[((((size_t)b * Cin + ci) * F + f) * H + iy) * W + ix];
+                const half8_t w = *reinterpret_cast<const half8_t*>(sw + ((ky * 3 + kx) * Cin + ci) * Cout + g * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v * (float)w[j];
+            }
+        }
+    }
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];
+    *reinterpret_cast<half8_t*>(y + m * Cout + g * 8) = o;
+}
+
+int launch_conv_in(const half_t* x, const half_t* wp, const float* bias, half_t* y, int B, int Cin, int F, int H, int W,
+                   int Cout, hipStream_t stream) {
+    LAVIE_CHECK(Cout % 8 == 0 && (9 * Cin * Cout) % 8 == 0, "conv_in: Cout must be a multiple of 8");
+    const size_t lds = (size_t)9 * Cin * Cout * sizeof(half_t);
+    LAVIE_CHECK(lds <= 64 * 1024, "conv_in: weights do not fit LDS (%zu B)", lds);
+    const long total = (long)B * F * H * W * (Cout / 8);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, stream, x, wp, bias, y, B,
+                       Cin, F, H, W, Cout);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ conv_out (unet.py:290,506)
+// channels-last [M, Cin] -> NCFHW [B, Cout<=8, F, H, W].  One wave per output pixel, K = 9*Cin split
+// over the lanes as 16-byte vectors; weights [Cout][tap][Cin] in LDS.
+constexpr int CONV_OUT_MAXC = 8;
+__global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wp,
+                                                      const float* __restrict__ bias, half_t* __restrict__ y, int B,
+                                                      int Cin, int F, int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* sw = reinterpret_cast<half_t*>(smem);
+    const int kk = 9 * Cin;
+    for (int i = threadIdx.x * 8; i < kk * Cout; i += 256 * 8)
+        *reinterpret_cast<half8_t*>(sw + i) = *reinterpret_cast<const half8_t*>(wp + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long M = (long)B * F * H * W;
+    if (m >= M) return;
+    const int xw = (int)(m % W);
+    const int yh = (int)((m / W) % H);
+    const long img = m / ((long)W * H);          // b * F + f
+    const int nvec = Cin >> 3;
+    float acc[CONV_OUT_MAXC];
+#pragma unroll
+    for (int c = 0; c < CONV_OUT_MAXC; ++c) acc[c] = 0.f;
+    for (int i = lane; i < 9 * nvec; i += 64) {
+        const int tap = i / nvec, vec = i - tap * nvec;
+        const int iy = yh + tap / 3 - 1, ix = xw + tap % 3 - 1;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+        const half8_t v = *reinterpret_cast<const half8_t*>(x + ((img * H + iy) * W + ix) * Cin + vec * 8);
+#pragma unroll
+        for (int c = 0; c < CONV_OUT_MAXC; ++c) {
+            if (c < Cout) {
+                const half8_t w = *reinterpret_cast<const half8_t*>(sw + (size_t)c * kk + tap * Cin + vec * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[c] += (float)v[j] * (float)w[j];
+            }
+        }
+    }
+    const int f = (int)(img % F);
+    const int b = (int)(img / F);
+#pragma unroll
+    for (int c = 0; c < CONV_OUT_MAXC; ++c) {
+        if (c < Cout) {
+            const float s = wave_sum(acc[c]) + bias[c];
+            if (lane == 0) y[((((size_t)b * Cout + c) * F + f) * H + yh) * W + xw] = (half_t)s;
+        }
+    }
+}
+
+int launch_conv_out(const half_t* x, const half_t* wp, const float* bias, half_t* y, int B, int Cin, int F, int H, int W,
+                    int Cout, hipStream_t stream) {
+    LAVIE_CHECK(Cout <= CONV_OUT_MAXC && Cin % 8 == 0, "conv_out: unsupported Cout=%d Cin=%d", Cout, Cin);
+    const size_t lds = (size_t)9 * Cin * Cout * sizeof(half_t);
+    LAVIE_CHECK(lds <= 64 * 1024, "conv_out: weights do not fit LDS (%zu B)", lds);
+    const long M = (long)B * F * H * W;
+    hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, stream, x, wp, bias, y, B, Cin, F,
+                       H, W, Cout);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ CFG + DDPM step
+// pipeline_videogen.py:679-683 with the scheduler arithmetic of oracle/ddpm.py (diffusers DDPMScheduler.step).
+__global__ void cfg_ddpm_step_kernel(const half_t* __restrict__ eps2, float* __restrict__ x,
+                                     const float* __restrict__ noise, half_t* __restrict__ model_in2, long n,
+                                     float guidance, float kx, float ke, float c0, float ct, float sigma) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float eu = (float)eps2[i], ec = (float)eps2[n + i];
+    const float eps = eu + guidance * (ec - eu);
+    const float xt = x[i];
+    const float x0 = kx * xt - ke * eps;
+    float xn = c0 * x0 + ct * xt;
+    if (sigma != 0.f) xn += sigma * noise[i];
+    x[i] = xn;
+    const half_t h = (half_t)xn;
+    model_in2[i] = h;
+    model_in2[n + i] = h;
+}
+
+int launch_cfg_ddpm_step(const half_t* eps2, float* x, const float* noise, half_t* model_in2, int64_t n, float guidance,
+                         float kx, float ke, float c0, float ct, float sigma, hipStream_t stream) {
+    LAVIE_CHECK(sigma == 0.f || noise != nullptr, "ddpm step: sigma != 0 needs a noise tensor");
+    hipLaunchKernelGGL(cfg_ddpm_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, eps2, x, noise,
+                       model_in2, (long)n, guidance, kx, ke, c0, ct, sigma);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void f32_to_f16_dup2_kernel(const float* __restrict__ x, half_t* __restrict__ out2, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const half_t h = (half_t)x[i];
+    out2[i] = h;
+    out2[n + i] = h;
+}
+
+int launch_f32_to_f16_dup2(const float* x, half_t* out2, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(f32_to_f16_dup2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, out2, (long)n);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ relative-position bias
+// RelativePositionBias (attention.py:669-707): out[h, i, j] = emb[bucket(i, j), h].
+void relpos_bucket_table(int F, int num_buckets, int max_distance, int* out) {
+    const int half_b = num_buckets / 2;
+    const int exact = half_b / 2;
+    for (int i = 0; i < F; ++i) {
+        for (int j = 0; j < F; ++j) {
+            int n = i - j;                         // -(k_pos - q_pos)
+            int b = n < 0 ? half_b : 0;            // key in the future
+            n = n < 0 ? -n : n;
+            if (n < exact) {
+                b += n;
+            } else {
+                // torch evaluates this in fp32; for every n < 128 that equals the exact value (tests/test_host_logic.py)
+                int v = exact + (int)floor(log((double)n / exact) / log((double)max_distance / exact) * (half_b - exact) + 1e-9);
+                b += v < half_b - 1 ? v : half_b - 1;
+            }
+            out[i * F + j] = b;
+        }
+    }
+}
+
+__global__ void fill_relpos_bias_kernel(const half_t* __restrict__ emb, const int* __restrict__ buckets,
+                                        float* __restrict__ out, int heads, int F) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= heads * F * F) return;
+    const int h = i / (F * F), ij = i - h * F * F;
+    out[i] = (float)emb[buckets[ij] * heads + h];
+}
+
+int launch_fill_relpos_bias(const half_t* emb, const int* buckets, float* out, int heads, int F, hipStream_t stream) {
+    const int n = heads * F * F;
+    hipLaunchKernelGGL(fill_relpos_bias_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, emb, buckets, out, heads, F);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ weight repacking (load time)
+// [Cout][Cin][3][3] -> out[co * ld_out + col0 + (ky*3+kx)*Cin + ci]
+__global__ void pack_conv3x3_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin, int ld_out,
+                                    int col0) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)Cout * Cin * 9;
+    if (i >= total) return;
+    const int ci = (int)(i % Cin);
+    const int tap = (int)((i / Cin) % 9);
+    const int co = (int)(i / ((long)Cin * 9));
+    out[(size_t)co * ld_out + col0 + tap * Cin + ci] = w[((size_t)co * Cin + ci) * 9 + tap];
+}
+
+int launch_pack_conv3x3(const half_t* w, half_t* out, int Cout, int Cin, int ld_out, int col0, hipStream_t stream) {
+    const long total = (long)Cout * Cin * 9;
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, out, Cout, Cin,
+                       ld_out, col0);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void copy_rows_kernel(const half_t* __restrict__ src, int ld_src, half_t* __restrict__ dst, int ld_dst,
+                                 int rows, int cols, int col0) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    dst[(size_t)r * ld_dst + col0 + c] = src[(size_t)r * ld_src + c];
+}
+
+int launch_copy_rows(const half_t* src, int ld_src, half_t* dst, int ld_dst, int rows, int cols, int col0,
+                     hipStream_t stream) {
+    const long total = (long)rows * cols;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, ld_src, dst,
+                       ld_dst, rows, cols, col0);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// GEGLU projection rows [value(0..N/2) ; gate(N/2..N)] -> 16-row blocks alternating value / gate, so that
+// the igemm epilogue finds h and its gate in the same lane (igemm.hip, EPI_GEGLU).
+__device__ __forceinline__ int geglu_src_row(int n, int N) {
+    const int j = n >> 5, i = n & 31;
+    return i < 16 ? 16 * j + i : N / 2 + 16 * j + (i - 16);
+}
+
+__global__ void pack_geglu_rows_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int N, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    out[i] = w[(size_t)geglu_src_row(n, N) * K + k];
+}
+
+int launch_pack_geglu_rows(const half_t* w, half_t* out, int N, int K, hipStream_t stream) {
+    LAVIE_CHECK(N % 32 == 0, "geglu pack: N must be a multiple of 32");
+    const long total = (long)N * K;
+    hipLaunchKernelGGL(pack_geglu_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, out, N, K);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void pack_geglu_bias_kernel(const half_t* __restrict__ b, float* __restrict__ out, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) out[n] = (float)b[geglu_src_row(n, N)];
+}
+
+int launch_pack_geglu_bias(const half_t* b, float* out, int N, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_geglu_bias_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, b, out, N);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void f16_to_f32_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, float* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)a[i] + (b ? (float)b[i] : 0.f);
+}
+
+int launch_f16_to_f32(const half_t* src, float* dst, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src,
+                       (const half_t*)nullptr, dst, (long)n);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_add_f16_to_f32(const half_t* a, const half_t* b, float* dst, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, dst, (long)n);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// conv_in weights [Cout][Cin][3][3] -> [(ky*3+kx)*Cin + ci][Cout]
+__global__ void pack_conv_in_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * Cin * 9) return;
+    const int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
+    out[(size_t)(tap * Cin + ci) * Cout + co] = w[i];
+}
+
+int launch_pack_conv_in(const half_t* w, half_t* out, int Cout, int Cin, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_conv_in_kernel, dim3(cdiv(Cout * Cin * 9, 256)), dim3(256), 0, stream, w, out, Cout, Cin);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace lavie

@@ -1,0 +1,780 @@
+// UNet3DConditionModel.forward on a HIP stream: weight packing, workspace planning, kernel sequencing.
+// Mirrors the wiring of /root/reference/base/models/unet.py:454-506 and unet_blocks.py
+// (226-232, 320-362, 417-441, 524-574, 625-648) on channels-last activations; see DESIGN.md.
+#include "engine.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace lavie {
+
+// ------------------------------------------------------------------ error text
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+#define RUN(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------------ arena
+DeviceArena::~DeviceArena() { free_all(); }
+
+void DeviceArena::free_all() {
+    for (void* p : chunks_) (void)hipFree(p);
+    chunks_.clear();
+    cur_ = nullptr;
+    cap_ = off_ = peak_ = total_ = 0;
+}
+
+int DeviceArena::init_fixed(size_t bytes) {
+    free_all();
+    fixed_ = true;
+    void* p = nullptr;
+    LAVIE_HIP(hipMalloc(&p, bytes));
+    chunks_.push_back(p);
+    cur_ = (char*)p;
+    cap_ = bytes;
+    total_ = bytes;
+    return 0;
+}
+
+void* DeviceArena::alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (virtual_) {
+        off_ += bytes;
+        if (off_ > peak_) peak_ = off_;
+        return (void*)(uintptr_t)256;   // never dereferenced
+    }
+    if (off_ + bytes > cap_) {
+        if (fixed_) return nullptr;
+        const size_t sz = bytes > kChunk ? bytes : kChunk;
+        void* p = nullptr;
+        if (hipMalloc(&p, sz) != hipSuccess) return nullptr;
+        chunks_.push_back(p);
+        cur_ = (char*)p;
+        cap_ = sz;
+        off_ = 0;
+        total_ += sz;
+    }
+    void* r = cur_ + off_;
+    off_ += bytes;
+    if (off_ > peak_) peak_ = off_;
+    return r;
+}
+
+// ------------------------------------------------------------------ model structure
+UNet::UNet(const lavie_unet_config& cfg) : cfg_(cfg) { build_param_list(); }
+UNet::~UNet() {}
+
+int UNet::validate_config() {
+    const lavie_unet_config& c = cfg_;
+    LAVIE_CHECK(c.num_levels >= 1 && c.num_levels <= LAVIE_MAX_LEVELS, "config: num_levels=%d", c.num_levels);
+    LAVIE_CHECK(c.in_channels >= 1 && c.in_channels <= 16 && c.out_channels >= 1 && c.out_channels <= 8,
+                "config: in/out channels %d/%d unsupported", c.in_channels, c.out_channels);
+    LAVIE_CHECK(c.heads >= 1 && c.layers_per_block >= 1 && c.norm_groups >= 1, "config: heads/layers/groups");
+    LAVIE_CHECK(c.cross_attention_dim % 64 == 0, "config: cross_attention_dim %d must be a multiple of 64", c.cross_attention_dim);
+    for (int l = 0; l < c.num_levels; ++l) {
+        const int w = c.block_out_channels[l];
+        LAVIE_CHECK(w % 64 == 0 && w % c.norm_groups == 0, "config: width %d must be a multiple of 64 and of norm_groups", w);
+        if (c.attn_levels[l]) {
+            LAVIE_CHECK(w % c.heads == 0 && (w / c.heads) % 8 == 0 && w / c.heads >= c.rotary_dim && w / c.heads <= 160,
+                        "config: width %d gives head dim %d (need multiple of 8, %d..160)", w, w / c.heads, c.rotary_dim);
+        }
+    }
+    LAVIE_CHECK(c.rotary_dim == 32 || c.rotary_dim == 16 || c.rotary_dim == 8, "config: rotary_dim %d", c.rotary_dim);
+    return 0;
+}
+
+void UNet::build_param_list() {
+    const lavie_unet_config& c = cfg_;
+    auto add = [&](const std::string& name, std::vector<int> shape) {
+        long long n = 1;
+        for (int s : shape) n *= s;
+        index_[name] = params_.size();
+        params_.push_back({name, shape, n});
+    };
+    auto affine = [&](const std::string& p, int ch) { add(p + ".weight", {ch}); add(p + ".bias", {ch}); };
+    auto conv = [&](const std::string& p, int cin, int cout, int k) { add(p + ".weight", {cout, cin, k, k}); add(p + ".bias", {cout}); };
+    auto lin = [&](const std::string& p, int cin, int cout, bool bias) { add(p + ".weight", {cout, cin}); if (bias) add(p + ".bias", {cout}); };
+    const int temb = c.block_out_channels[0] * 4;
+    int temb_total = 0;
+    auto resnet = [&](const std::string& p, int cin, int cout) {
+        affine(p + ".norm1", cin);
+        conv(p + ".conv1", cin, cout, 3);
+        lin(p + ".time_emb_proj", temb, cout, true);
+        affine(p + ".norm2", cout);
+        conv(p + ".conv2", cout, cout, 3);
+        if (cin != cout) conv(p + ".conv_shortcut", cin, cout, 1);
+        ResnetW r;
+        r.prefix = p; r.cin = cin; r.cout = cout; r.shortcut = cin != cout; r.temb_off = temb_total;
+        temb_total += cout;
+        resnets_.push_back(r);
+    };
+    auto attention = [&](const std::string& p, int ch, int kv) {
+        lin(p + ".to_q", ch, ch, false); lin(p + ".to_k", kv, ch, false); lin(p + ".to_v", kv, ch, false);
+        lin(p + ".to_out.0", ch, ch, true);
+    };
+    auto transformer = [&](const std::string& p, int ch) {
+        affine(p + ".norm", ch);
+        conv(p + ".proj_in", ch, ch, 1);
+        const std::string b = p + ".transformer_blocks.0";
+        attention(b + ".attn1", ch, ch);
+        affine(b + ".norm1", ch);
+        attention(b + ".attn2", ch, c.cross_attention_dim);
+        affine(b + ".norm2", ch);
+        attention(b + ".attn_temp", ch, ch);
+        add(b + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight", {c.rel_buckets, c.heads});
+        add(b + ".attn_temp.rotary_emb.freqs", {c.rotary_dim / 2});
+        affine(b + ".norm_temp", ch);
+        lin(b + ".ff.net.0.proj", ch, 8 * ch, true);
+        lin(b + ".ff.net.2", 4 * ch, ch, true);
+        affine(b + ".norm3", ch);
+        conv(p + ".proj_out", ch, ch, 1);
+        TransformerW t;
+        t.prefix = p; t.C = ch;
+        transformers_.push_back(t);
+    };
+    const int* widths = c.block_out_channels;
+    const int L = c.num_levels;
+    conv("conv_in", c.in_channels, widths[0], 3);
+    lin("time_embedding.linear_1", widths[0], temb, true);
+    lin("time_embedding.linear_2", temb, temb, true);
+    std::vector<int> skips{widths[0]};
+    int cur = widths[0];
+    for (int l = 0; l < L; ++l) {
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            const std::string p = "down_blocks." + std::to_string(l);
+            resnet(p + ".resnets." + std::to_string(j), cur, widths[l]);
+            cur = widths[l];
+            if (c.attn_levels[l]) transformer(p + ".attentions." + std::to_string(j), cur);
+            skips.push_back(cur);
+        }
+        if (l + 1 < L) {
+            conv("down_blocks." + std::to_string(l) + ".downsamplers.0.conv", cur, cur, 3);
+            skips.push_back(cur);
+        }
+    }
+    resnet("mid_block.resnets.0", cur, cur);
+    transformer("mid_block.attentions.0", cur);
+    resnet("mid_block.resnets.1", cur, cur);
+    for (int i = 0; i < L; ++i) {
+        const int l = L - 1 - i;
+        const std::string p = "up_blocks." + std::to_string(i);
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            const int sk = skips.back();
+            skips.pop_back();
+            resnet(p + ".resnets." + std::to_string(j), cur + sk, widths[l]);
+            cur = widths[l];
+            if (c.attn_levels[l]) transformer(p + ".attentions." + std::to_string(j), cur);
+        }
+        if (i + 1 < L) conv(p + ".upsamplers.0.conv", cur, cur, 3);
+    }
+    affine("conv_norm_out", widths[0]);
+    conv("conv_out", widths[0], c.out_channels, 3);
+    given_.assign(params_.size(), nullptr);
+    tproj_.N = temb_total;
+    tproj_.K = temb;
+}
+
+int UNet::set_param(const char* name, const void* data, long long numel) {
+    auto it = index_.find(name);
+    LAVIE_CHECK(it != index_.end(), "set_param: unknown state-dict key '%s'", name);
+    const ParamInfo& pi = params_[it->second];
+    LAVIE_CHECK(pi.numel == numel, "set_param: '%s' has %lld elements, expected %lld", name, numel, pi.numel);
+    LAVIE_CHECK(data != nullptr, "set_param: '%s' null data", name);
+    given_[it->second] = (const half_t*)data;
+    return 0;
+}
+
+const half_t* UNet::given(const std::string& name) const {
+    auto it = index_.find(name);
+    return it == index_.end() ? nullptr : given_[it->second];
+}
+
+// ------------------------------------------------------------------ weight packing
+#define NEED(ptr, name) LAVIE_CHECK((ptr) != nullptr, "finalize: missing state-dict tensor '%s'", (name).c_str())
+#define WALLOC(var, type, count)                                                                  \
+    do {                                                                                          \
+        (var) = (type*)weights_.alloc((size_t)(count) * sizeof(type));                            \
+        LAVIE_CHECK((var) != nullptr, "finalize: out of device memory (%zu B)", (size_t)(count) * sizeof(type)); \
+    } while (0)
+
+int UNet::pack_norm(const std::string& prefix, int C, NormW* out, hipStream_t s) {
+    const half_t* g = given(prefix + ".weight");
+    const half_t* b = given(prefix + ".bias");
+    NEED(g, prefix + ".weight");
+    NEED(b, prefix + ".bias");
+    out->C = C;
+    WALLOC(out->g, float, C);
+    WALLOC(out->b, float, C);
+    RUN(launch_f16_to_f32(g, out->g, C, s));
+    RUN(launch_f16_to_f32(b, out->b, C, s));
+    return 0;
+}
+
+int UNet::pack_linear(const std::string& prefix, int N, int K, bool bias, LinW* out, hipStream_t s) {
+    const half_t* w = given(prefix + ".weight");
+    NEED(w, prefix + ".weight");
+    out->N = N;
+    out->K = K;
+    WALLOC(out->w, half_t, (size_t)N * K);
+    LAVIE_HIP(hipMemcpyAsync(out->w, w, (size_t)N * K * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+    out->b = nullptr;
+    if (bias) {
+        const half_t* b = given(prefix + ".bias");
+        NEED(b, prefix + ".bias");
+        WALLOC(out->b, float, N);
+        RUN(launch_f16_to_f32(b, out->b, N, s));
+    }
+    return 0;
+}
+
+int UNet::pack_resnet(ResnetW* r, hipStream_t s) {
+    const std::string& p = r->prefix;
+    RUN(pack_norm(p + ".norm1", r->cin, &r->n1, s));
+    RUN(pack_norm(p + ".norm2", r->cout, &r->n2, s));
+    const half_t* w1 = given(p + ".conv1.weight");
+    const half_t* b1 = given(p + ".conv1.bias");
+    const half_t* w2 = given(p + ".conv2.weight");
+    const half_t* b2 = given(p + ".conv2.bias");
+    NEED(w1, p + ".conv1.weight"); NEED(b1, p + ".conv1.bias"); NEED(w2, p + ".conv2.weight"); NEED(b2, p + ".conv2.bias");
+    WALLOC(r->w1, half_t, (size_t)r->cout * 9 * r->cin);
+    RUN(launch_pack_conv3x3(w1, r->w1, r->cout, r->cin, 9 * r->cin, 0, s));
+    WALLOC(r->b1, float, r->cout);
+    RUN(launch_f16_to_f32(b1, r->b1, r->cout, s));
+    r->ldw2 = 9 * r->cout + (r->shortcut ? r->cin : 0);
+    WALLOC(r->w2, half_t, (size_t)r->cout * r->ldw2);
+    RUN(launch_pack_conv3x3(w2, r->w2, r->cout, r->cout, r->ldw2, 0, s));
+    WALLOC(r->b2, float, r->cout);
+    if (r->shortcut) {
+        const half_t* ws = given(p + ".conv_shortcut.weight");
+        const half_t* bs = given(p + ".conv_shortcut.bias");
+        NEED(ws, p + ".conv_shortcut.weight"); NEED(bs, p + ".conv_shortcut.bias");
+        RUN(launch_copy_rows(ws, r->cin, r->w2, r->ldw2, r->cout, r->cin, 9 * r->cout, s));
+        RUN(launch_add_f16_to_f32(b2, bs, r->b2, r->cout, s));
+    } else {
+        RUN(launch_f16_to_f32(b2, r->b2, r->cout, s));
+    }
+    // fused time_emb_proj rows
+    const half_t* wt = given(p + ".time_emb_proj.weight");
+    const half_t* bt = given(p + ".time_emb_proj.bias");
+    NEED(wt, p + ".time_emb_proj.weight"); NEED(bt, p + ".time_emb_proj.bias");
+    LAVIE_HIP(hipMemcpyAsync(tproj_.w + (size_t)r->temb_off * tproj_.K, wt, (size_t)r->cout * tproj_.K * sizeof(half_t),
+                             hipMemcpyDeviceToDevice, s));
+    RUN(launch_f16_to_f32(bt, tproj_.b + r->temb_off, r->cout, s));
+    return 0;
+}
+
+int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
+    const std::string& p = t->prefix;
+    const std::string b = p + ".transformer_blocks.0";
+    const int C = t->C, X = cfg_.cross_attention_dim;
+    RUN(pack_norm(p + ".norm", C, &t->gn, s));
+    RUN(pack_linear(p + ".proj_in", C, C, true, &t->pin, s));      // [C, C, 1, 1] == [C, C]
+    RUN(pack_linear(p + ".proj_out", C, C, true, &t->pout, s));
+    RUN(pack_norm(b + ".norm1", C, &t->ln1, s));
+    RUN(pack_norm(b + ".norm2", C, &t->ln2, s));
+    RUN(pack_norm(b + ".norm_temp", C, &t->lnt, s));
+    RUN(pack_norm(b + ".norm3", C, &t->ln3, s));
+    auto fuse = [&](const std::string& a, const char* const* names, int count, int K, half_t** out) -> int {
+        WALLOC(*out, half_t, (size_t)count * C * K);
+        for (int i = 0; i < count; ++i) {
+            const std::string key = a + "." + names[i] + ".weight";
+            const half_t* w = given(key);
+            NEED(w, key);
+            LAVIE_HIP(hipMemcpyAsync(*out + (size_t)i * C * K, w, (size_t)C * K * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+        }
+        return 0;
+    };
+    static const char* const qkv[] = {"to_q", "to_k", "to_v"};
+    static const char* const kv[] = {"to_k", "to_v"};
+    static const char* const qonly[] = {"to_q"};
+    RUN(fuse(b + ".attn1", qkv, 3, C, &t->wqkv1));
+    RUN(pack_linear(b + ".attn1.to_out.0", C, C, true, &t->o1, s));
+    RUN(fuse(b + ".attn2", qonly, 1, C, &t->wq2));
+    RUN(fuse(b + ".attn2", kv, 2, X, &t->wkv2));
+    RUN(pack_linear(b + ".attn2.to_out.0", C, C, true, &t->o2, s));
+    RUN(fuse(b + ".attn_temp", qkv, 3, C, &t->wqkvt));
+    RUN(pack_linear(b + ".attn_temp.to_out.0", C, C, true, &t->ot, s));
+    {
+        const std::string key = b + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight";
+        const half_t* e = given(key);
+        NEED(e, key);
+        const size_t n = (size_t)cfg_.rel_buckets * cfg_.heads;
+        WALLOC(t->relemb, half_t, n);
+        LAVIE_HIP(hipMemcpyAsync(t->relemb, e, n * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+        // `...rotary_emb.freqs` is accepted by set_param and ignored: angles are always derived in
+        // fp32 from rotary_dim (SURVEY.md §8c decision; an fp16 copy of freqs would be lossy).
+    }
+    {
+        const half_t* w = given(b + ".ff.net.0.proj.weight");
+        const half_t* bias = given(b + ".ff.net.0.proj.bias");
+        NEED(w, b + ".ff.net.0.proj.weight"); NEED(bias, b + ".ff.net.0.proj.bias");
+        t->ff1.N = 8 * C; t->ff1.K = C;
+        WALLOC(t->ff1.w, half_t, (size_t)8 * C * C);
+        WALLOC(t->ff1.b, float, 8 * C);
+        RUN(launch_pack_geglu_rows(w, t->ff1.w, 8 * C, C, s));
+        RUN(launch_pack_geglu_bias(bias, t->ff1.b, 8 * C, s));
+    }
+    RUN(pack_linear(b + ".ff.net.2", C, 4 * C, true, &t->ff2, s));
+    return 0;
+}
+
+int UNet::pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s) {
+    const half_t* w = given(prefix + ".weight");
+    const half_t* b = given(prefix + ".bias");
+    NEED(w, prefix + ".weight"); NEED(b, prefix + ".bias");
+    out->C = C;
+    WALLOC(out->w, half_t, (size_t)C * 9 * C);
+    WALLOC(out->b, float, C);
+    RUN(launch_pack_conv3x3(w, out->w, C, C, 9 * C, 0, s));
+    RUN(launch_f16_to_f32(b, out->b, C, s));
+    return 0;
+}
+
+int UNet::finalize(hipStream_t s) {
+    RUN(validate_config());
+    LAVIE_CHECK(!finalized_, "finalize: already finalized");
+    const lavie_unet_config& c = cfg_;
+    const int C0 = c.block_out_channels[0];
+    WALLOC(zero_page_, half_t, 256);
+    LAVIE_HIP(hipMemsetAsync(zero_page_, 0, 512, s));
+    {   // conv_in / conv_out / conv_norm_out
+        const half_t* w = given("conv_in.weight");
+        const half_t* b = given("conv_in.bias");
+        NEED(w, std::string("conv_in.weight")); NEED(b, std::string("conv_in.bias"));
+        WALLOC(conv_in_w_, half_t, (size_t)9 * c.in_channels * C0);
+        WALLOC(conv_in_b_, float, C0);
+        RUN(launch_pack_conv_in(w, conv_in_w_, C0, c.in_channels, s));
+        RUN(launch_f16_to_f32(b, conv_in_b_, C0, s));
+        const half_t* wo = given("conv_out.weight");
+        const half_t* bo = given("conv_out.bias");
+        NEED(wo, std::string("conv_out.weight")); NEED(bo, std::string("conv_out.bias"));
+        WALLOC(conv_out_w_, half_t, (size_t)c.out_channels * 9 * C0);
+        WALLOC(conv_out_b_, float, c.out_channels);
+        RUN(launch_pack_conv3x3(wo, conv_out_w_, c.out_channels, C0, 9 * C0, 0, s));
+        RUN(launch_f16_to_f32(bo, conv_out_b_, c.out_channels, s));
+        RUN(pack_norm("conv_norm_out", C0, &norm_out_, s));
+    }
+    RUN(pack_linear("time_embedding.linear_1", C0 * 4, C0, true, &time1_, s));
+    RUN(pack_linear("time_embedding.linear_2", C0 * 4, C0 * 4, true, &time2_, s));
+    WALLOC(tproj_.w, half_t, (size_t)tproj_.N * tproj_.K);
+    WALLOC(tproj_.b, float, tproj_.N);
+    for (ResnetW& r : resnets_) RUN(pack_resnet(&r, s));
+    for (TransformerW& t : transformers_) RUN(pack_transformer(&t, s));
+    const int L = c.num_levels;
+    downs_.resize(L > 1 ? L - 1 : 0);
+    ups_.resize(L > 1 ? L - 1 : 0);
+    for (int l = 0; l + 1 < L; ++l)
+        RUN(pack_sampler("down_blocks." + std::to_string(l) + ".downsamplers.0.conv", c.block_out_channels[l], &downs_[l], s));
+    for (int i = 0; i + 1 < L; ++i)
+        RUN(pack_sampler("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", c.block_out_channels[L - 1 - i], &ups_[i], s));
+    relbias_.assign(transformers_.size(), nullptr);
+    finalized_ = true;
+    return 0;
+}
+
+int UNet::ensure_tables(int F, hipStream_t s) {
+    if (tables_F_ == F) return 0;
+    const int rp = cfg_.rotary_dim / 2;
+    std::vector<float> hc((size_t)F * rp), hs((size_t)F * rp);
+    for (int f = 0; f < F; ++f)
+        for (int k = 0; k < rp; ++k) {
+            const float freq = (float)pow(10000.0, -2.0 * k / cfg_.rotary_dim);
+            const float ang = (float)f * freq;
+            hc[(size_t)f * rp + k] = (float)cos((double)ang);
+            hs[(size_t)f * rp + k] = (float)sin((double)ang);
+        }
+    std::vector<int> hb((size_t)F * F);
+    relpos_bucket_table(F, cfg_.rel_buckets, cfg_.rel_max_distance, hb.data());
+    WALLOC(rot_cos_, float, (size_t)F * rp);
+    WALLOC(rot_sin_, float, (size_t)F * rp);
+    WALLOC(buckets_dev_, int, (size_t)F * F);
+    // pageable host memory: these copies complete before returning (tables are rebuilt only when F changes)
+    LAVIE_HIP(hipMemcpy(rot_cos_, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice));
+    LAVIE_HIP(hipMemcpy(rot_sin_, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
+    LAVIE_HIP(hipMemcpy(buckets_dev_, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice));
+    for (size_t i = 0; i < transformers_.size(); ++i) {
+        WALLOC(relbias_[i], float, (size_t)cfg_.heads * F * F);
+        RUN(launch_fill_relpos_bias(transformers_[i].relemb, buckets_dev_, relbias_[i], cfg_.heads, F, s));
+    }
+    LAVIE_HIP(hipStreamSynchronize(s));
+    tables_F_ = F;
+    return 0;
+}
+
+// ------------------------------------------------------------------ forward
+struct FwdCtx {
+    hipStream_t s;
+    DeviceArena* ws;
+    bool dry;               // plan only: allocate, launch nothing
+    int B, F, ctx_len;
+    float* stats_pool;      // zeroed once per forward
+    size_t stats_off, stats_cap;
+};
+
+#define LAUNCH(expr)              \
+    do {                          \
+        if (!c.dry) RUN(expr);    \
+    } while (0)
+
+#define WS(var, type, count)                                                                                     \
+    type* var = (type*)c.ws->alloc((size_t)(count) * sizeof(type));                                              \
+    LAVIE_CHECK(var != nullptr, "workspace exhausted: call lavie_unet_prepare for this shape (needed %zu more B)", \
+                (size_t)(count) * sizeof(type))
+
+static float* take_stats(FwdCtx& c, size_t n) {
+    float* p = c.stats_pool + c.stats_off;
+    c.stats_off += n;
+    return c.stats_off <= c.stats_cap ? p : nullptr;
+}
+
+static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const float* bias, int N, int K, const half_t* R,
+                  half_t* C, int ldc, int M, int epilogue = EPI_LINEAR) {
+    if (c.dry) return 0;
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = lda; p.W = W; p.ldw = K; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldc;
+    p.M = M; p.N = N; p.nk = K / IGEMM_BK;
+    LAVIE_CHECK(K % IGEMM_BK == 0, "linear: K=%d must be a multiple of %d", K, IGEMM_BK);
+    return launch_igemm(p, false, epilogue, c.s);
+}
+
+// 3x3 conv (pad 1) over `nsrc` channel-concatenated sources, plus optional centre-tap shortcut sources.
+static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsrc, const half_t* const* sc, const int* scC,
+                   int nsc, const half_t* W, int ldw, const float* bias, const float* bias2, int ldb2, int rows_per_batch,
+                   const half_t* R, half_t* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const half_t* zero) {
+    if (c.dry) return 0;
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.W = W; p.ldw = ldw; p.C = y; p.ldc = Cout; p.bias = bias; p.bias2 = bias2; p.ldb2 = ldb2;
+    p.rows_per_batch = rows_per_batch; p.R = R; p.ldr = Cout;
+    p.Hi = Hi; p.Wi = Wi; p.stride = stride; p.ups = ups;
+    p.Ho = ups ? Hi * 2 : (Hi - 1) / stride + 1;
+    p.Wo = ups ? Wi * 2 : (Wi - 1) / stride + 1;
+    p.M = NI * p.Ho * p.Wo;
+    p.N = Cout;
+    p.zero = zero;
+    int ns = 0, nk = 0;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int i = 0; i < nsrc; ++i) {
+            LAVIE_CHECK(srcC[i] % IGEMM_BK == 0, "conv3x3: channel count %d must be a multiple of %d", srcC[i], IGEMM_BK);
+            IgemmSeg& sg = p.seg[ns++];
+            sg.src = src[i]; sg.C = srcC[i]; sg.c0 = 0; sg.nchunks = srcC[i] / IGEMM_BK;
+            sg.dy = tap / 3 - 1; sg.dx = tap % 3 - 1;
+            nk += sg.nchunks;
+        }
+    for (int i = 0; i < nsc; ++i) {
+        LAVIE_CHECK(scC[i] % IGEMM_BK == 0 && stride == 1 && ups == 0, "conv3x3: bad shortcut source");
+        IgemmSeg& sg = p.seg[ns++];
+        sg.src = sc[i]; sg.C = scC[i]; sg.c0 = 0; sg.nchunks = scC[i] / IGEMM_BK; sg.dy = 0; sg.dx = 0;
+        nk += sg.nchunks;
+    }
+    LAVIE_CHECK(ns <= IGEMM_MAX_SEG, "conv3x3: too many K segments (%d)", ns);
+    LAVIE_CHECK(nk * IGEMM_BK == ldw, "conv3x3: weight row length %d does not match gathered K %d", ldw, nk * IGEMM_BK);
+    p.nseg = ns;
+    p.nk = nk;
+    return launch_igemm(p, true, EPI_LINEAR, c.s);
+}
+
+int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, const float* tproj,
+                     int ld_tproj, half_t* y, int H, int W) {
+    LAVIE_CHECK(C1 + C2 == r.cin, "resnet %s: got %d+%d input channels, expected %d", r.prefix.c_str(), C1, C2, r.cin);
+    const int G = cfg_.norm_groups;
+    const int NI = c.B * c.F;
+    const int P = c.F * H * W;            // rows sharing GroupNorm statistics: the whole video (resnet.py:180)
+    const size_t M = (size_t)NI * H * W;
+    const size_t mark = c.ws->mark();
+    WS(nrm, half_t, M * r.cin);
+    WS(h1, half_t, M * r.cout);
+    WS(n2, half_t, M * r.cout);
+    float* st1 = take_stats(c, (size_t)c.B * G * 2);
+    float* st2 = take_stats(c, (size_t)c.B * G * 2);
+    LAVIE_CHECK(st1 && st2, "resnet: statistics pool exhausted");
+    LAUNCH(launch_gn_stats(x1, C1, x2, C2, c.B, P, G, st1, c.s));
+    LAUNCH(launch_gn_apply(x1, C1, x2, C2, c.B, P, G, st1, r.n1.g, r.n1.b, cfg_.norm_eps, true, nrm, c.s));
+    {
+        const half_t* src[1] = {nrm};
+        const int srcC[1] = {r.cin};
+        RUN(conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, r.w1, 9 * r.cin, r.b1, tproj, ld_tproj, P, nullptr, h1, NI, H, W,
+                    r.cout, 1, 0, zero_page_));
+    }
+    LAUNCH(launch_gn_stats(h1, r.cout, nullptr, 0, c.B, P, G, st2, c.s));
+    LAUNCH(launch_gn_apply(h1, r.cout, nullptr, 0, c.B, P, G, st2, r.n2.g, r.n2.b, cfg_.norm_eps, true, n2, c.s));
+    {
+        const half_t* src[1] = {n2};
+        const int srcC[1] = {r.cout};
+        const half_t* sc[2] = {x1, x2};
+        const int scC[2] = {C1, C2};
+        const int nsc = r.shortcut ? (x2 ? 2 : 1) : 0;
+        RUN(conv3x3(c, src, srcC, 1, sc, scC, nsc, r.w2, r.ldw2, r.b2, nullptr, 0, 1, r.shortcut ? nullptr : x1, y, NI, H, W,
+                    r.cout, 1, 0, zero_page_));
+    }
+    c.ws->release(mark);
+    return 0;
+}
+
+int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W) {
+    const int C = t.C, G = cfg_.norm_groups, heads = cfg_.heads, dh = C / heads;
+    const int NI = c.B * c.F, D = H * W;
+    const int T = NI * D;
+    const int X = cfg_.cross_attention_dim;
+    const float scale = 1.0f / sqrtf((float)dh);
+    const size_t mark = c.ws->mark();
+    WS(tx, half_t, (size_t)T * C);
+    WS(ln, half_t, (size_t)T * C);
+    WS(att, half_t, (size_t)T * C);
+    WS(wide, half_t, (size_t)T * 4 * C);          // qkv [T,3C] / GEGLU output [T,4C] / q2 [T,C]
+    WS(kv2, half_t, (size_t)c.B * c.ctx_len * 2 * C);
+    float* st = take_stats(c, (size_t)NI * G * 2);
+    LAVIE_CHECK(st, "transformer: statistics pool exhausted");
+    const size_t ti = &t - transformers_.data();
+
+    // per-frame GroupNorm (eps 1e-6) + 1x1 proj_in (attention.py:369-373)
+    LAUNCH(launch_gn_stats(x, C, nullptr, 0, NI, D, G, st, c.s));
+    LAUNCH(launch_gn_apply(x, C, nullptr, 0, NI, D, G, st, t.gn.g, t.gn.b, 1e-6f, false, ln, c.s));
+    RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, T));
+
+    // spatial self-attention (attention.py:513-522)
+    LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, T, C, 1e-5f, c.s));
+    RUN(linear(c, ln, C, t.wqkv1, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+    if (!c.dry) {
+        AttnParams a;
+        a.q = wide; a.ldq = 3 * C; a.k = wide + C; a.ldk = 3 * C; a.v = wide + 2 * C; a.ldv = 3 * C;
+        a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = D; a.heads = heads; a.dh = dh; a.kv_batch_div = 1; a.scale = scale;
+        RUN(launch_attention(a, c.s));
+    }
+    RUN(linear(c, att, C, t.o1.w, t.o1.b, C, C, tx, tx, C, T));
+
+    // text cross-attention (attention.py:524-534); K/V once per video instead of once per frame (364)
+    LAUNCH(launch_layernorm(tx, t.ln2.g, t.ln2.b, ln, T, C, 1e-5f, c.s));
+    RUN(linear(c, ln, C, t.wq2, nullptr, C, C, nullptr, wide, C, T));
+    RUN(linear(c, ctx, X, t.wkv2, nullptr, 2 * C, X, nullptr, kv2, 2 * C, c.B * c.ctx_len));
+    if (!c.dry) {
+        AttnParams a;
+        a.q = wide; a.ldq = C; a.k = kv2; a.ldk = 2 * C; a.v = kv2 + C; a.ldv = 2 * C;
+        a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = c.ctx_len; a.heads = heads; a.dh = dh; a.kv_batch_div = c.F; a.scale = scale;
+        RUN(launch_attention(a, c.s));
+    }
+    RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T));
+
+    // temporal self-attention over frames, tokens stay in (b f) d order (attention.py:548-555)
+    LAUNCH(launch_layernorm(tx, t.lnt.g, t.lnt.b, ln, T, C, 1e-5f, c.s));
+    RUN(linear(c, ln, C, t.wqkvt, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+    if (!c.dry) {
+        TemporalParams tp;
+        tp.qkv = wide; tp.ld = 3 * C; tp.o = att; tp.ldo = C; tp.B = c.B; tp.F = c.F; tp.D = D; tp.heads = heads; tp.dh = dh;
+        tp.bias = relbias_[ti]; tp.rot_cos = rot_cos_; tp.rot_sin = rot_sin_; tp.rot_dim = cfg_.rotary_dim; tp.scale = scale;
+        RUN(launch_temporal_attention(tp, c.s));
+    }
+    RUN(linear(c, att, C, t.ot.w, t.ot.b, C, C, tx, tx, C, T));
+
+    // GEGLU feed-forward (attention.py:558)
+    LAUNCH(launch_layernorm(tx, t.ln3.g, t.ln3.b, ln, T, C, 1e-5f, c.s));
+    RUN(linear(c, ln, C, t.ff1.w, t.ff1.b, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU));
+    RUN(linear(c, wide, 4 * C, t.ff2.w, t.ff2.b, C, 4 * C, tx, tx, C, T));
+
+    // 1x1 proj_out + residual, in place on the block input (attention.py:394-401)
+    RUN(linear(c, tx, C, t.pout.w, t.pout.b, C, C, x, x, C, T));
+    c.ws->release(mark);
+    return 0;
+}
+
+int UNet::run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups) {
+    const half_t* src[1] = {x};
+    const int srcC[1] = {C};
+    return conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, w.w, 9 * C, w.b, nullptr, 0, 1, nullptr, y, c.B * c.F, Hi, Wi, C, stride,
+                   ups, zero_page_);
+}
+
+int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out) {
+    const lavie_unet_config& cfg = cfg_;
+    const int L = cfg.num_levels;
+    const int NI = c.B * c.F;
+    const int C0 = cfg.block_out_channels[0];
+    const int temb = C0 * 4;
+    const int G = cfg.norm_groups;
+
+    // statistics pool: every GroupNorm instance gets its own zeroed slot, one memset per forward
+    c.stats_cap = (size_t)(resnets_.size() * 2 + 1) * c.B * G * 2 + transformers_.size() * (size_t)NI * G * 2;
+    {
+        WS(pool, float, c.stats_cap);
+        c.stats_pool = pool;
+        c.stats_off = 0;
+        if (!c.dry) LAVIE_HIP(hipMemsetAsync(pool, 0, c.stats_cap * sizeof(float), c.s));
+    }
+
+    // time embedding (unet.py:428-434) and all 22 resnet projections in one GEMV (resnet.py:186)
+    WS(tsin, float, (size_t)c.B * C0);
+    WS(e1, float, (size_t)c.B * temb);
+    WS(emb, float, (size_t)c.B * temb);
+    WS(tproj, float, (size_t)c.B * tproj_.N);
+    LAUNCH(launch_timestep_sinusoid(timesteps, tsin, c.B, C0, c.s));
+    LAUNCH(launch_gemv(tsin, time1_.w, time1_.b, e1, c.B, temb, C0, 0, 1, c.s));
+    LAUNCH(launch_gemv(e1, time2_.w, time2_.b, emb, c.B, temb, temb, 0, 0, c.s));
+    LAUNCH(launch_gemv(emb, tproj_.w, tproj_.b, tproj, c.B, tproj_.N, temb, 1, 0, c.s));
+
+    std::vector<int> Hs(L), Ws(L);
+    for (int l = 0; l < L; ++l) {
+        Hs[l] = l == 0 ? prep_H_ : (Hs[l - 1] - 1) / 2 + 1;
+        Ws[l] = l == 0 ? prep_W_ : (Ws[l - 1] - 1) / 2 + 1;
+    }
+    // prep_H_/prep_W_ hold the CURRENT call's size while run() executes (set by forward()/prepare())
+    auto rows = [&](int l) { return (size_t)NI * Hs[l] * Ws[l]; };
+
+    struct Skip { half_t* p; int C; };
+    std::vector<Skip> skips;
+    size_t ri = 0, ti = 0;
+
+    WS(x0, half_t, rows(0) * C0);
+    LAUNCH(launch_conv_in(sample, conv_in_w_, conv_in_b_, x0, c.B, cfg.in_channels, c.F, Hs[0], Ws[0], C0, c.s));
+    half_t* x = x0;
+    int C = C0;
+    skips.push_back({x, C});
+
+    for (int l = 0; l < L; ++l) {
+        for (int j = 0; j < cfg.layers_per_block; ++j) {
+            const ResnetW& r = resnets_[ri++];
+            WS(y, half_t, rows(l) * r.cout);
+            RUN(run_resnet(c, r, x, C, nullptr, 0, tproj + r.temb_off, tproj_.N, y, Hs[l], Ws[l]));
+            x = y; C = r.cout;
+            if (cfg.attn_levels[l]) RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l]));
+            skips.push_back({x, C});
+        }
+        if (l + 1 < L) {
+            WS(y, half_t, rows(l + 1) * C);
+            RUN(run_conv(c, x, C, downs_[l], y, Hs[l], Ws[l], 2, 0));
+            x = y;
+            skips.push_back({x, C});
+        }
+    }
+    {
+        const int l = L - 1;
+        const ResnetW& r0 = resnets_[ri++];
+        WS(y0, half_t, rows(l) * r0.cout);
+        RUN(run_resnet(c, r0, x, C, nullptr, 0, tproj + r0.temb_off, tproj_.N, y0, Hs[l], Ws[l]));
+        x = y0; C = r0.cout;
+        RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l]));
+        const ResnetW& r1 = resnets_[ri++];
+        WS(y1, half_t, rows(l) * r1.cout);
+        RUN(run_resnet(c, r1, x, C, nullptr, 0, tproj + r1.temb_off, tproj_.N, y1, Hs[l], Ws[l]));
+        x = y1; C = r1.cout;
+    }
+    for (int i = 0; i < L; ++i) {
+        const int l = L - 1 - i;
+        for (int j = 0; j < cfg.layers_per_block + 1; ++j) {
+            const Skip sk = skips.back();
+            skips.pop_back();
+            const ResnetW& r = resnets_[ri++];
+            WS(y, half_t, rows(l) * r.cout);
+            RUN(run_resnet(c, r, x, C, sk.p, sk.C, tproj + r.temb_off, tproj_.N, y, Hs[l], Ws[l]));
+            x = y; C = r.cout;
+            if (cfg.attn_levels[l]) RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l]));
+        }
+        if (i + 1 < L) {
+            WS(y, half_t, rows(l - 1) * C);
+            RUN(run_conv(c, x, C, ups_[i], y, Hs[l], Ws[l], 1, 1));
+            x = y;
+        }
+    }
+    // conv_norm_out + SiLU + conv_out (unet.py:504-506), back to the caller's NCFHW layout
+    {
+        float* st = take_stats(c, (size_t)c.B * G * 2);
+        LAVIE_CHECK(st, "statistics pool exhausted");
+        WS(nrm, half_t, rows(0) * C0);
+        const int P = c.F * Hs[0] * Ws[0];
+        LAUNCH(launch_gn_stats(x, C0, nullptr, 0, c.B, P, G, st, c.s));
+        LAUNCH(launch_gn_apply(x, C0, nullptr, 0, c.B, P, G, st, norm_out_.g, norm_out_.b, cfg.norm_eps, true, nrm, c.s));
+        LAUNCH(launch_conv_out(nrm, conv_out_w_, conv_out_b_, out, c.B, C0, c.F, Hs[0], Ws[0], cfg.out_channels, c.s));
+    }
+    return 0;
+}
+
+static int check_shape(const lavie_unet_config& cfg, int B, int F, int H, int W, int ctx_len) {
+    LAVIE_CHECK(B >= 1 && B <= 8 && F >= 1 && F <= 16 && H >= 1 && W >= 1 && ctx_len >= 1,
+                "shape: B=%d (1..8) F=%d (1..16) H=%d W=%d ctx_len=%d unsupported", B, F, H, W, ctx_len);
+    const int div = 1 << (cfg.num_levels - 1);
+    LAVIE_CHECK(H % div == 0 && W % div == 0, "shape: H=%d W=%d must be multiples of %d (unet.py:393-401 upsample-size "
+                "forwarding is not implemented)", H, W, div);
+    return 0;
+}
+
+int UNet::prepare(int B, int F, int H, int W, int ctx_len) {
+    LAVIE_CHECK(finalized_, "prepare: call lavie_unet_finalize first");
+    RUN(check_shape(cfg_, B, F, H, W, ctx_len));
+    DeviceArena plan;
+    plan.init_virtual();
+    FwdCtx c{nullptr, &plan, true, B, F, ctx_len, nullptr, 0, 0};
+    prep_H_ = H; prep_W_ = W;
+    RUN(run(c, nullptr, nullptr, nullptr, nullptr));
+    const size_t need = plan.peak() + (1 << 20);
+    if (need > ws_.total_bytes()) RUN(ws_.init_fixed(need));
+    prep_B_ = B; prep_F_ = F; prep_ctx_ = ctx_len;
+    return 0;
+}
+
+int UNet::forward(const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out, int B, int F, int H, int W,
+                  int ctx_len, hipStream_t stream) {
+    LAVIE_CHECK(finalized_, "forward: call lavie_unet_finalize first");
+    LAVIE_CHECK(sample && timesteps && ctx && out, "forward: null tensor");
+    RUN(check_shape(cfg_, B, F, H, W, ctx_len));
+    LAVIE_CHECK(ws_.total_bytes() > 0, "forward: call lavie_unet_prepare first");
+    RUN(ensure_tables(F, stream));
+    ws_.release(0);
+    FwdCtx c{stream, &ws_, false, B, F, ctx_len, nullptr, 0, 0};
+    prep_H_ = H; prep_W_ = W;
+    return run(c, sample, timesteps, ctx, out);
+}
+
+int UNet::resnet_forward(const char* prefix, const half_t* x1, int C1, const half_t* x2, int C2, const float* temb, half_t* y,
+                         int B, int F, int H, int W, hipStream_t stream) {
+    LAVIE_CHECK(finalized_, "resnet_forward: call lavie_unet_finalize first");
+    const ResnetW* r = nullptr;
+    for (const ResnetW& cand : resnets_) if (cand.prefix == prefix) r = &cand;
+    LAVIE_CHECK(r != nullptr, "resnet_forward: no ResnetBlock3D with prefix '%s'", prefix);
+    // standalone call: private workspace sized on the fly (test seam, not the hot path)
+    DeviceArena local;
+    const size_t M = (size_t)B * F * H * W;
+    RUN(local.init_fixed((M * (r->cin + 2 * r->cout)) * sizeof(half_t) + (size_t)B * r->cout * 4 + (4 << 20)));
+    FwdCtx c{stream, &local, false, B, F, 0, nullptr, 0, 0};
+    c.stats_cap = (size_t)2 * B * cfg_.norm_groups * 2;
+    c.stats_pool = (float*)local.alloc(c.stats_cap * sizeof(float));
+    LAVIE_HIP(hipMemsetAsync(c.stats_pool, 0, c.stats_cap * sizeof(float), stream));
+    float* tproj = (float*)local.alloc((size_t)B * r->cout * sizeof(float));
+    RUN(launch_gemv(temb, tproj_.w + (size_t)r->temb_off * tproj_.K, tproj_.b + r->temb_off, tproj, B, r->cout, tproj_.K, 1, 0, stream));
+    RUN(run_resnet(c, *r, x1, C1, C2 ? x2 : nullptr, C2, tproj, r->cout, y, H, W));
+    LAVIE_HIP(hipStreamSynchronize(stream));     // the private workspace dies with this frame
+    return 0;
+}
+
+int UNet::transformer_forward(const char* prefix, half_t* x, const half_t* ctx, int B, int F, int H, int W, int ctx_len,
+                              hipStream_t stream) {
+    LAVIE_CHECK(finalized_, "transformer_forward: call lavie_unet_finalize first");
+    const TransformerW* t = nullptr;
+    for (const TransformerW& cand : transformers_) if (cand.prefix == prefix) t = &cand;
+    LAVIE_CHECK(t != nullptr, "transformer_forward: no Transformer3DModel with prefix '%s'", prefix);
+    LAVIE_CHECK(F >= 1 && F <= 16, "transformer_forward: F=%d unsupported", F);
+    RUN(ensure_tables(F, stream));
+    DeviceArena local;
+    const size_t T = (size_t)B * F * H * W;
+    RUN(local.init_fixed(T * t->C * 7 * sizeof(half_t) + (size_t)B * ctx_len * 2 * t->C * sizeof(half_t) + (4 << 20)));
+    FwdCtx c{stream, &local, false, B, F, ctx_len, nullptr, 0, 0};
+    c.stats_cap = (size_t)B * F * cfg_.norm_groups * 2;
+    c.stats_pool = (float*)local.alloc(c.stats_cap * sizeof(float));
+    LAVIE_HIP(hipMemsetAsync(c.stats_pool, 0, c.stats_cap * sizeof(float), stream));
+    RUN(run_transformer(c, *t, x, ctx, H, W));
+    LAVIE_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+}  // namespace lavie

@@ -1,0 +1,129 @@
+// Host-side denoiser: owns packed weights + workspace and enqueues one UNet forward on a stream.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lavie_hip.h"
+#include "common.h"
+#include "ops.h"
+
+namespace lavie {
+
+// Bump allocator over hipMalloc'd chunks (weights) or one fixed block (workspace).
+class DeviceArena {
+public:
+    ~DeviceArena();
+    int init_fixed(size_t bytes);                 // one block, alloc() fails when exhausted
+    void init_virtual() { virtual_ = true; }      // no memory: only tracks the high-water mark
+    void* alloc(size_t bytes);                    // 256-B aligned; nullptr on failure
+    size_t mark() const { return off_; }
+    void release(size_t mark) { off_ = mark; }
+    size_t peak() const { return peak_; }
+    size_t total_bytes() const { return total_; }
+    void free_all();
+
+private:
+    std::vector<void*> chunks_;
+    char* cur_ = nullptr;
+    size_t cap_ = 0, off_ = 0, peak_ = 0, total_ = 0;
+    bool fixed_ = false, virtual_ = false;
+    static constexpr size_t kChunk = 512ull << 20;
+};
+
+struct ParamInfo {
+    std::string name;
+    std::vector<int> shape;
+    long long numel;
+};
+
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct LinW { half_t* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
+
+struct ResnetW {
+    std::string prefix;
+    int cin = 0, cout = 0;
+    bool shortcut = false;
+    NormW n1, n2;
+    half_t* w1 = nullptr; float* b1 = nullptr;      // [cout][9*cin]
+    half_t* w2 = nullptr; float* b2 = nullptr;      // [cout][9*cout (+ cin)] ; b2 = conv2.bias (+ shortcut.bias)
+    int ldw2 = 0;
+    int temb_off = 0;                               // column of this block inside the fused time_emb_proj output
+};
+
+struct TransformerW {
+    std::string prefix;
+    int C = 0;
+    NormW gn, ln1, ln2, lnt, ln3;
+    LinW pin, pout;
+    half_t* wqkv1 = nullptr; LinW o1;
+    half_t* wq2 = nullptr; half_t* wkv2 = nullptr; LinW o2;
+    half_t* wqkvt = nullptr; LinW ot;
+    half_t* relemb = nullptr;                       // [buckets][heads] fp16 (state-dict tensor)
+    LinW ff1, ff2;                                  // ff1 in GEGLU-interleaved row order
+};
+
+struct SamplerW { half_t* w = nullptr; float* b = nullptr; int C = 0; };
+
+struct FwdCtx;   // per-call state (engine.cpp)
+
+class UNet {
+public:
+    explicit UNet(const lavie_unet_config& cfg);
+    ~UNet();
+    int validate_config();
+    const std::vector<ParamInfo>& params() const { return params_; }
+    int set_param(const char* name, const void* data, long long numel);
+    int finalize(hipStream_t stream);
+    int prepare(int B, int F, int H, int W, int ctx_len);
+    int forward(const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out, int B, int F, int H, int W,
+                int ctx_len, hipStream_t stream);
+    int resnet_forward(const char* prefix, const half_t* x1, int C1, const half_t* x2, int C2, const float* temb, half_t* y,
+                       int B, int F, int H, int W, hipStream_t stream);
+    int transformer_forward(const char* prefix, half_t* x, const half_t* ctx, int B, int F, int H, int W, int ctx_len,
+                            hipStream_t stream);
+    long long weight_bytes() const { return (long long)weights_.total_bytes(); }
+    long long workspace_bytes() const { return (long long)ws_.total_bytes(); }
+
+private:
+    void build_param_list();
+    const half_t* given(const std::string& name) const;
+    int pack_norm(const std::string& prefix, int C, NormW* out, hipStream_t s);
+    int pack_linear(const std::string& prefix, int N, int K, bool bias, LinW* out, hipStream_t s);
+    int pack_resnet(ResnetW* r, hipStream_t s);
+    int pack_transformer(TransformerW* t, hipStream_t s);
+    int pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s);
+    int ensure_tables(int F, hipStream_t s);
+
+    int run(FwdCtx& c, const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out);
+    int run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, const float* tproj,
+                   int ld_tproj, half_t* y, int H, int W);
+    int run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W);
+    int run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups);
+
+    lavie_unet_config cfg_;
+    std::vector<ParamInfo> params_;
+    std::unordered_map<std::string, size_t> index_;
+    std::vector<const half_t*> given_;
+    bool finalized_ = false;
+
+    DeviceArena weights_, ws_;
+    // packed model
+    half_t* conv_in_w_ = nullptr; float* conv_in_b_ = nullptr;
+    half_t* conv_out_w_ = nullptr; float* conv_out_b_ = nullptr;
+    NormW norm_out_;
+    LinW time1_, time2_, tproj_;                    // tproj_: all ResnetBlock3D.time_emb_proj stacked
+    std::vector<ResnetW> resnets_;                  // execution order
+    std::vector<TransformerW> transformers_;
+    std::vector<SamplerW> downs_, ups_;
+    half_t* zero_page_ = nullptr;
+    // per-F tables
+    int tables_F_ = 0;
+    float* rot_cos_ = nullptr; float* rot_sin_ = nullptr;
+    int* buckets_dev_ = nullptr;
+    std::vector<float*> relbias_;                   // one [heads, F, F] per transformer
+    // prepared geometry
+    int prep_B_ = 0, prep_F_ = 0, prep_H_ = 0, prep_W_ = 0, prep_ctx_ = 0;
+};
+
+}  // namespace lavie

@@ -1,0 +1,261 @@
+// GroupNorm (two reduction domains) and LayerNorm on channels-last fp16 activations.
+//
+// Reference ops replaced:
+//   * nn.GroupNorm on the 5-D video tensor — statistics over (C/G, F, H, W), i.e. ACROSS frames
+//     (resnet.py:180,191; unet.py:504), followed by SiLU (resnet.py:181,197; unet.py:505);
+//   * nn.GroupNorm per frame, eps 1e-6, no activation (attention.py:324,369);
+//   * nn.LayerNorm(C) (attention.py:442,459,474,480).
+// Both GroupNorm domains use the same two kernels: the caller chooses what a "batch" is
+// (video: NB = B, P = F*h*w rows; per frame: NB = B*F, P = h*w rows).  The input may be the
+// virtual channel concatenation [x1 | x2] of the up path (unet_blocks.py:538): a group may
+// straddle the two tensors, and only the normalised result is ever materialised.
+//
+// All three are HBM-bound: 16-byte vector accesses, fp32 statistics, wave/LDS reductions.
+#include "common.h"
+#include "ops.h"
+
+namespace lavie {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_C = 4096;
+
+struct GnGeom {
+    int nvec;   // (C1 + C2) / 8
+    int tx;     // channel-vector lanes
+    int vpt;    // vectors per thread (nvec = tx * vpt)
+    int ty;     // row lanes = GN_THREADS / tx
+};
+
+static bool gn_geometry(int ctot, GnGeom* g) {
+    if (ctot % 8 != 0 || ctot > GN_MAX_C) return false;
+    g->nvec = ctot / 8;
+    g->vpt = 1;
+    while (g->nvec / g->vpt > GN_THREADS || g->nvec % g->vpt != 0) {
+        if (++g->vpt > 4) return false;
+    }
+    g->tx = g->nvec / g->vpt;
+    g->ty = GN_THREADS / g->tx;
+    return true;
+}
+
+__device__ __forceinline__ const half_t* gn_src(const half_t* x1, int C1, const half_t* x2, int C2, size_t row, int c) {
+    return c < C1 ? x1 + row * C1 + c : x2 + row * C2 + (c - C1);
+}
+
+// stats[nb][g][0..1] += (sum, sum of squares) of this block's slab.  `stats` must be zero on entry.
+template <int VPT>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const half_t* __restrict__ x1, int C1,
+                                                             const half_t* __restrict__ x2, int C2, int P,
+                                                             int rows_per_slab, int groups, int tx, int ty,
+                                                             float* __restrict__ stats) {
+    __shared__ float s_sum[GN_MAX_C];
+    __shared__ float s_sq[GN_MAX_C];
+    const int ctot = C1 + C2;
+    const int nb = blockIdx.y;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < ctot; c += GN_THREADS) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+    __syncthreads();
+
+    const int vx = tid % tx, vy = tid / tx;
+    const int r0 = blockIdx.x * rows_per_slab;
+    const int r1 = min(P, r0 + rows_per_slab);
+    if (vy < ty) {
+        float s[VPT][8], q[VPT][8];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[v][j] = 0.f; q[v][j] = 0.f; }
+        for (int r = r0 + vy; r < r1; r += ty) {
+            const size_t row = (size_t)nb * P + r;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int c = (vx + v * tx) * 8;
+                const half8_t h = *reinterpret_cast<const half8_t*>(gn_src(x1, C1, x2, C2, row, c));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)h[j]; s[v][j] += f; q[v][j] += f * f; }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int c = (vx + v * tx) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&s_sum[c + j], s[v][j]); atomicAdd(&s_sq[c + j], q[v][j]); }
+        }
+    }
+    __syncthreads();
+    const int cpg = ctot / groups;
+    for (int g = tid; g < groups; g += GN_THREADS) {
+        float a = 0.f, b = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += s_sum[c]; b += s_sq[c]; }
+        float* dst = stats + ((size_t)nb * groups + g) * 2;
+        atomicAdd(dst, a);
+        atomicAdd(dst + 1, b);
+    }
+}
+
+// y[row, :] = act((x - mean_g) * rstd_g * gamma + beta) for the slab, y is [NB*P, C1+C2] row-major.
+template <int VPT, bool SILU>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __restrict__ x1, int C1,
+                                                             const half_t* __restrict__ x2, int C2, int P,
+                                                             int rows_per_slab, int groups, int tx, int ty,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             half_t* __restrict__ y) {
+    __shared__ float s_a[GN_MAX_C];
+    __shared__ float s_b[GN_MAX_C];
+    const int ctot = C1 + C2;
+    const int cpg = ctot / groups;
+    const int nb = blockIdx.y;
+    const int tid = threadIdx.x;
+    const float inv_count = 1.0f / ((float)P * (float)cpg);
+    for (int c = tid; c < ctot; c += GN_THREADS) {
+        const float* st = stats + ((size_t)nb * groups + c / cpg) * 2;
+        const float mean = st[0] * inv_count;
+        const float var = fmaxf(st[1] * inv_count - mean * mean, 0.f);
+        const float a = rsqrtf(var + eps) * gamma[c];
+        s_a[c] = a;
+        s_b[c] = beta[c] - mean * a;
+    }
+    __syncthreads();
+    const int vx = tid % tx, vy = tid / tx;
+    if (vy >= ty) return;
+    const int r0 = blockIdx.x * rows_per_slab;
+    const int r1 = min(P, r0 + rows_per_slab);
+    for (int r = r0 + vy; r < r1; r += ty) {
+        const size_t row = (size_t)nb * P + r;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int c = (vx + v * tx) * 8;
+            const half8_t h = *reinterpret_cast<const half8_t*>(gn_src(x1, C1, x2, C2, row, c));
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)h[j] * s_a[c + j] + s_b[c + j];
+                if (SILU) f = silu_f(f);
+                o[j] = (half_t)f;
+            }
+            *reinterpret_cast<half8_t*>(y + row * ctot + c) = o;
+        }
+    }
+}
+
+static int gn_slabs(int P, int NB, int ty, int* rows_per_slab) {
+    int slabs = cdiv(P, ty * 4);                 // at least 4 rows per row-lane
+    const int cap = NB >= 2048 ? 1 : 2048 / NB;  // ~2k blocks fill 256 CUs x 8
+    if (slabs > cap) slabs = cap;
+    if (slabs < 1) slabs = 1;
+    *rows_per_slab = cdiv(P, slabs);
+    return cdiv(P, *rows_per_slab);
+}
+
+int launch_gn_stats(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, float* stats,
+                    hipStream_t stream) {
+    GnGeom g;
+    const int ctot = C1 + C2;
+    LAVIE_CHECK(gn_geometry(ctot, &g), "group_norm: unsupported channel count %d", ctot);
+    LAVIE_CHECK(C1 % 8 == 0 && C2 % 8 == 0 && ctot % groups == 0 && groups <= GN_THREADS, "group_norm: bad channels/groups");
+    int rps;
+    const int slabs = gn_slabs(P, NB, g.ty, &rps);
+    dim3 grid(slabs, NB);
+#define LAVIE_GN_STATS(V) \
+    hipLaunchKernelGGL(gn_stats_kernel<V>, grid, dim3(GN_THREADS), 0, stream, x1, C1, x2, C2, P, rps, groups, g.tx, g.ty, stats)
+    switch (g.vpt) {
+        case 1: LAVIE_GN_STATS(1); break;
+        case 2: LAVIE_GN_STATS(2); break;
+        case 3: LAVIE_GN_STATS(3); break;
+        default: LAVIE_GN_STATS(4); break;
+    }
+#undef LAVIE_GN_STATS
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gn_apply(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* stats,
+                    const float* gamma, const float* beta, float eps, bool silu, half_t* y, hipStream_t stream) {
+    GnGeom g;
+    const int ctot = C1 + C2;
+    LAVIE_CHECK(gn_geometry(ctot, &g), "group_norm: unsupported channel count %d", ctot);
+    LAVIE_CHECK(C1 % 8 == 0 && C2 % 8 == 0 && ctot % groups == 0, "group_norm: bad channels/groups");
+    int rps;
+    const int slabs = gn_slabs(P, NB, g.ty, &rps);
+    dim3 grid(slabs, NB);
+#define LAVIE_GN_APPLY(V, S)                                                                                      \
+    hipLaunchKernelGGL((gn_apply_kernel<V, S>), grid, dim3(GN_THREADS), 0, stream, x1, C1, x2, C2, P, rps, groups, \
+                       g.tx, g.ty, stats, gamma, beta, eps, y)
+#define LAVIE_GN_APPLY_V(V) \
+    if (silu) LAVIE_GN_APPLY(V, true); else LAVIE_GN_APPLY(V, false)
+    switch (g.vpt) {
+        case 1: LAVIE_GN_APPLY_V(1); break;
+        case 2: LAVIE_GN_APPLY_V(2); break;
+        case 3: LAVIE_GN_APPLY_V(3); break;
+        default: LAVIE_GN_APPLY_V(4); break;
+    }
+#undef LAVIE_GN_APPLY_V
+#undef LAVIE_GN_APPLY
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- LayerNorm
+// One wave per token row; the row stays in registers between the mean and the variance pass.
+constexpr int LN_MAX_VEC = 4;   // C <= 4 * 64 * 8 = 2048
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, half_t* __restrict__ y,
+                                                       int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 3;
+    const half_t* xr = x + (size_t)row * C;
+    half8_t v[LN_MAX_VEC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            v[i] = *reinterpret_cast<const half8_t*>(xr + vi * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += (float)v[i][j];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        if (lane + i * 64 < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)v[i][j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    half_t* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_VEC; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            half8_t o;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + vi * 8);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + vi * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + vi * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + vi * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (half_t)(((float)v[i][j] - mean) * rstd * g0[j] + b0[j]);
+                o[j + 4] = (half_t)(((float)v[i][j + 4] - mean) * rstd * g1[j] + b1[j]);
+            }
+            *reinterpret_cast<half8_t*>(yr + vi * 8) = o;
+        }
+    }
+}
+
+int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* y, int rows, int C, float eps,
+                     hipStream_t stream) {
+    LAVIE_CHECK(C % 8 == 0 && C <= LN_MAX_VEC * 64 * 8, "layer_norm: unsupported width %d", C);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, gamma, beta, y, rows, C, eps);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace lavie

@@ -1,0 +1,75 @@
+// Internal launcher declarations (host side).  Every launcher enqueues on `stream`, performs no
+// allocation or synchronisation (hipGraph-capturable), and returns 0 or a negative status with
+// the message available through lavie::get_error().
+#pragma once
+#include "common.h"
+#include "igemm.h"
+
+namespace lavie {
+
+// ---- norm.hip
+int launch_gn_stats(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, float* stats,
+                    hipStream_t stream);
+int launch_gn_apply(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* stats,
+                    const float* gamma, const float* beta, float eps, bool silu, half_t* y, hipStream_t stream);
+int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* y, int rows, int C, float eps,
+                     hipStream_t stream);
+
+// ---- attention.hip : softmax(scale q k^T) v, heads packed along the channel axis
+struct AttnParams {
+    const half_t* q; int ldq;        // [NBq * Lq, ...] rows; head h at columns h*dh
+    const half_t* k; int ldk;        // [NBkv * Lk, ...]
+    const half_t* v; int ldv;
+    half_t* o; int ldo;              // [NBq * Lq, heads*dh]
+    int NBq, Lq, Lk, heads, dh;
+    int kv_batch_div;                // kv batch index = q batch index / kv_batch_div (text ctx shared by the frames)
+    float scale;
+};
+int launch_attention(const AttnParams& p, hipStream_t stream);
+
+// ---- temporal_attention.hip
+struct TemporalParams {
+    const half_t* qkv; int ld;       // [(b f) d, 3C]: q | k | v per token, token order (b, f, pixel)
+    half_t* o; int ldo;              // [(b f) d, C]
+    int B, F, D, heads, dh;          // D = pixels per frame
+    const float* bias;               // [heads, F, F] relative-position bias (query i, key j)
+    const float* rot_cos;            // [F, rot_dim/2]
+    const float* rot_sin;
+    int rot_dim;
+    float scale;
+};
+int launch_temporal_attention(const TemporalParams& p, hipStream_t stream);
+
+// ---- elementwise.hip
+int launch_timestep_sinusoid(const float* t, float* out, int B, int dim, hipStream_t stream);
+// out[b, n] = act_out(sum_k act_in(in[b, k]) * W[n, k] + bias[n]);  act: 0 none, 1 SiLU
+int launch_gemv(const float* in, const half_t* W, const float* bias, float* out, int B, int N, int K, int act_in,
+                int act_out, hipStream_t stream);
+// x [B, Cin, F, H, W] (NCFHW fp16) -> y [(B F) H W, Cout] channels-last, 3x3 pad 1; w packed [3*3*Cin][Cout]
+int launch_conv_in(const half_t* x, const half_t* wp, const float* bias, half_t* y, int B, int Cin, int F, int H, int W,
+                   int Cout, hipStream_t stream);
+// x [(B F) H W, Cin] channels-last -> y [B, Cout, F, H, W] NCFHW fp16, 3x3 pad 1; w packed [Cout][3*3][Cin]
+int launch_conv_out(const half_t* x, const half_t* wp, const float* bias, half_t* y, int B, int Cin, int F, int H, int W,
+                    int Cout, hipStream_t stream);
+// Classifier-free guidance + DDPM ancestral step (pipeline_videogen.py:679-683):
+//   eps = eps_u + s (eps_c - eps_u); x0 = kx x - ke eps; x' = c0 x0 + ct x + sigma noise
+//   writes x' (fp32, in place allowed) and the duplicated fp16 model input [2, n] for the next step.
+int launch_cfg_ddpm_step(const half_t* eps2, float* x, const float* noise, half_t* model_in2, int64_t n, float guidance,
+                         float kx, float ke, float c0, float ct, float sigma, hipStream_t stream);
+int launch_f32_to_f16_dup2(const float* x, half_t* out2, int64_t n, hipStream_t stream);
+int launch_fill_relpos_bias(const half_t* emb, const int* buckets, float* out, int heads, int F, hipStream_t stream);
+
+// ---- pack.hip : one-off weight repacking at load time
+int launch_pack_conv3x3(const half_t* w, half_t* out, int Cout, int Cin, int ld_out, int col0, hipStream_t stream);
+int launch_copy_rows(const half_t* src, int ld_src, half_t* dst, int ld_dst, int rows, int cols, int col0,
+                     hipStream_t stream);
+int launch_pack_geglu_rows(const half_t* w, half_t* out, int N, int K, hipStream_t stream);
+int launch_pack_geglu_bias(const half_t* b, float* out, int N, hipStream_t stream);
+int launch_f16_to_f32(const half_t* src, float* dst, int64_t n, hipStream_t stream);
+int launch_add_f16_to_f32(const half_t* a, const half_t* b, float* dst, int64_t n, hipStream_t stream);
+int launch_pack_conv_in(const half_t* w, half_t* out, int Cout, int Cin, hipStream_t stream);
+
+// host-only helper (no GPU): T5-style bucket of (query i, key j), attention.py:681-699
+void relpos_bucket_table(int F, int num_buckets, int max_distance, int* out);
+
+}  // namespace lavie

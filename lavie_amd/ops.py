@@ -1,0 +1,195 @@
+"""Operator-level entry points (the finer seam of SURVEY.md §8b) over the C ABI.
+
+All tensors are CUDA(HIP) fp16, channels-last: a reference video tensor `[b, c, f, h, w]` is the
+row-major matrix `[(b f h w), c]`, which is also the reference's token layout `(b f) (h w) c`.
+Every function enqueues on torch's current stream and raises RuntimeError on failure."""
+import ctypes
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk16(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
+            raise ValueError("expected contiguous fp16 device tensors")
+
+
+def _chk32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("expected contiguous fp32 device tensors")
+
+
+def to_rows(x: torch.Tensor) -> torch.Tensor:
+    """[b, c, f, h, w] -> channels-last rows [(b f h w), c] (a copy)."""
+    b, c, f, h, w = x.shape
+    return x.permute(0, 2, 3, 4, 1).reshape(b * f * h * w, c).contiguous()
+
+
+def from_rows(rows: torch.Tensor, b: int, f: int, h: int, w: int) -> torch.Tensor:
+    """channels-last rows [(b f h w), c] -> [b, c, f, h, w] (a copy)."""
+    return rows.reshape(b, f, h, w, -1).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def linear(a, weight, bias=None, residual=None, bias2=None, rows_per_batch=0, geglu=False, out=None):
+    """a[M,K] @ weight[N,K]^T (+bias fp32[N]) (+bias2 fp32[M/rows_per_batch, N]) (+residual[M,N])."""
+    _chk16(a, weight, residual, out)
+    _chk32(bias, bias2)
+    M, K = a.shape
+    N = weight.shape[0]
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.float16, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.lavie_linear_f16(_p(a), K, _p(weight), _p(bias), _p(bias2), N, rows_per_batch, _p(residual), n_out,
+                                    _p(out), n_out, M, N, K, int(geglu), _stream()), "lavie_linear_f16")
+    return out
+
+
+def pack_geglu(weight, bias):
+    """GEGLU projection [2*inner, K] -> the value/gate 16-row interleave the geglu epilogue expects."""
+    _chk16(weight, bias)
+    N, K = weight.shape
+    w_out = torch.empty_like(weight)
+    b_out = torch.empty(N, dtype=torch.float32, device=weight.device)
+    _lib.check(_lib.load().lavie_pack_geglu_f16(_p(weight), _p(bias), _p(w_out), _p(b_out), N, K, _stream()))
+    return w_out, b_out
+
+
+def pack_conv3x3(weight, shortcut_weight=None):
+    """[Cout, Cin, 3, 3] (+ optional 1x1 shortcut [Cout, Csc, 1, 1]) -> [Cout, 9*Cin (+ Csc)]."""
+    _chk16(weight, shortcut_weight)
+    cout, cin = weight.shape[:2]
+    csc = 0 if shortcut_weight is None else shortcut_weight.shape[1]
+    ld = 9 * cin + csc
+    out = torch.empty(cout, ld, dtype=torch.float16, device=weight.device)
+    _lib.check(_lib.load().lavie_pack_conv3x3_f16(_p(weight), _p(out), cout, cin, ld, 0, _stream()))
+    if csc:
+        out[:, 9 * cin:] = shortcut_weight.reshape(cout, csc)
+    return out
+
+
+_zero_pages = {}
+
+
+def _zero_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.float16, device=device)
+        _zero_pages[device] = z
+    return z
+
+
+def conv3x3(x1, wp, bias, ni, hi, wi, x2=None, sc1=None, sc2=None, bias2=None, rows_per_batch=0, residual=None,
+            stride=1, ups=0):
+    """Per-frame 3x3 conv, pad 1, on channels-last rows [(ni hi wi), C]; see lavie_conv3x3_f16."""
+    _chk16(x1, x2, sc1, sc2, wp, residual)
+    _chk32(bias, bias2)
+    cout = wp.shape[0]
+    ho = hi * 2 if ups else (hi - 1) // stride + 1
+    wo = wi * 2 if ups else (wi - 1) // stride + 1
+    y = torch.empty(ni * ho * wo, cout, dtype=torch.float16, device=x1.device)
+    c = lambda t: 0 if t is None else t.shape[1]
+    lib = _lib.load()
+    _lib.check(lib.lavie_conv3x3_f16(_p(x1), c(x1), _p(x2), c(x2), _p(sc1), c(sc1), _p(sc2), c(sc2), _p(wp), _p(bias),
+                                     _p(bias2), cout, rows_per_batch, _p(residual), _p(y), ni, hi, wi, cout, stride, ups,
+                                     _p(_zero_page(x1.device)), _stream()), "lavie_conv3x3_f16")
+    return y
+
+
+def group_norm(x1, gamma, beta, nb, groups, eps, silu, x2=None):
+    """GroupNorm (+SiLU) over rows; `nb` batches share statistics over rows/nb rows each."""
+    _chk16(x1, x2)
+    _chk32(gamma, beta)
+    rows = x1.shape[0]
+    c1, c2 = x1.shape[1], 0 if x2 is None else x2.shape[1]
+    y = torch.empty(rows, c1 + c2, dtype=torch.float16, device=x1.device)
+    ws = torch.empty(nb * groups * 2, dtype=torch.float32, device=x1.device)
+    _lib.check(_lib.load().lavie_group_norm_f16(_p(x1), c1, _p(x2), c2, nb, rows // nb, groups, _p(gamma), _p(beta),
+                                                float(eps), int(silu), _p(ws), _p(y), _stream()), "lavie_group_norm_f16")
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    _chk16(x)
+    _chk32(gamma, beta)
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().lavie_layer_norm_f16(_p(x), _p(gamma), _p(beta), _p(y), x.shape[0], x.shape[1], float(eps),
+                                                _stream()), "lavie_layer_norm_f16")
+    return y
+
+
+def attention(q, k, v, nb, lq, lk, heads, kv_batch_div=1, scale=None):
+    """q [nb*lq, *], k/v [(nb/kv_batch_div)*lk, *] may be column slices of wider row-major tensors."""
+    for t in (q, k, v):
+        if not (t.is_cuda and t.dtype == torch.float16 and t.stride(1) == 1):
+            raise ValueError("attention operands must be fp16 device tensors with unit column stride")
+    c = q.shape[1]
+    dh = c // heads
+    o = torch.empty(nb * lq, c, dtype=torch.float16, device=q.device)
+    scale = dh ** -0.5 if scale is None else scale
+    _lib.check(_lib.load().lavie_attention_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), c, nb,
+                                               lq, lk, heads, dh, kv_batch_div, float(scale), _stream()),
+               "lavie_attention_f16")
+    return o
+
+
+def relpos_buckets(frames: int, num_buckets: int = 32, max_distance: int = 32) -> torch.Tensor:
+    """Host-side bucket table [F, F] (query i, key j) — needs no GPU."""
+    buf = (ctypes.c_int * (frames * frames))()
+    _lib.check(_lib.load().lavie_relpos_buckets(frames, num_buckets, max_distance, buf), "lavie_relpos_buckets")
+    return torch.tensor(list(buf), dtype=torch.int64).reshape(frames, frames)
+
+
+def rotary_tables(frames: int, rot_dim: int = 32, theta: float = 10000.0, device="cuda"):
+    """cos/sin [F, rot_dim/2] in fp32 (angles = frame * theta^(-2k/rot_dim))."""
+    inv = theta ** (-torch.arange(0, rot_dim, 2, dtype=torch.float32) / rot_dim)
+    ang = torch.arange(frames, dtype=torch.float32).reshape(-1, 1) * inv.reshape(1, -1)
+    return ang.cos().to(device).contiguous(), ang.sin().to(device).contiguous()
+
+
+def temporal_attention(qkv, b, frames, d, heads, bias, rot_cos, rot_sin, rot_dim=32, scale=None):
+    """qkv [(b f d), 3C] (q | k | v) in (b, f, pixel) token order -> [(b f d), C]."""
+    _chk16(qkv)
+    _chk32(bias, rot_cos, rot_sin)
+    c = qkv.shape[1] // 3
+    dh = c // heads
+    o = torch.empty(qkv.shape[0], c, dtype=torch.float16, device=qkv.device)
+    scale = dh ** -0.5 if scale is None else scale
+    _lib.check(_lib.load().lavie_temporal_attention_f16(_p(qkv), 3 * c, _p(o), c, b, frames, d, heads, dh, _p(bias),
+                                                        _p(rot_cos), _p(rot_sin), rot_dim, float(scale), _stream()),
+               "lavie_temporal_attention_f16")
+    return o
+
+
+def cfg_ddpm_step(eps2, x, noise, model_in2, guidance, coeffs):
+    """Fused CFG + DDPM update; `coeffs` = (k_x, k_eps, c_x0, c_xt, sigma) from DDPMScheduler.coefficients."""
+    _chk16(eps2, model_in2)
+    _chk32(x, noise)
+    k_x, k_e, c_x0, c_xt, sigma = coeffs
+    n = x.numel()
+    _lib.check(_lib.load().lavie_cfg_ddpm_step(_p(eps2), _p(x), _p(noise), _p(model_in2), n, float(guidance), float(k_x),
+                                               float(k_e), float(c_x0), float(c_xt), float(sigma), _stream()),
+               "lavie_cfg_ddpm_step")
+
+
+def latents_to_model_input(x, model_in2):
+    _chk32(x)
+    _chk16(model_in2)
+    _lib.check(_lib.load().lavie_latents_to_model_input(_p(x), _p(model_in2), x.numel(), _stream()))

@@ -1,0 +1,202 @@
+"""Host-side mirror of `base/pipelines/pipeline_videogen.py` (reference): `VideoGenPipeline`.
+
+Keeps the reference call surface (`__call__` keywords, `prompt_embeds=` / `negative_prompt_embeds=` /
+`latents=` / `generator=` / `callback`, pipeline_videogen.py:512-535) and its loop semantics
+(662-689): CFG batch [negative | prompt], `u + s (c - u)`, DDPM ancestral step.  The loop body runs
+on the MI355X: the UNet through liblavie_hip.so and CFG + scheduler step as one fused kernel.
+CLIP text encoding and VAE decoding are NOT part of this package's compute path: pass any stock
+PyTorch-ROCm `tokenizer`/`text_encoder`/`vae` objects to use them, or work with embeddings and
+`output_type="latent"` (what the benchmark measures: video-latents/s)."""
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import torch
+
+from . import ops
+from .scheduling_ddpm import DDPMScheduler, randn_tensor
+
+
+@dataclass
+class StableDiffusionPipelineOutput:
+    video: torch.Tensor
+
+
+class VideoGenPipeline:
+    def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, scheduler=None, clip_model=None,
+                 clip_processor=None):
+        if unet is None:
+            raise ValueError("unet is required")
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.unet = unet
+        self.scheduler = scheduler or DDPMScheduler()
+        self.vae_scale_factor = 8                        # 2 ** (len(vae.config.block_out_channels) - 1) for SD-1.x
+        self._copy_stream = None
+
+    def to(self, device):
+        self.unet.to(device)
+        for m in (self.vae, self.text_encoder):
+            if m is not None:
+                m.to(device)
+        return self
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    # ------------------------------------------------------------------ prompt handling (273-420)
+    def _encode_prompt(self, prompt, device, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds,
+                       negative_prompt_embeds):
+        if prompt_embeds is None:
+            if self.tokenizer is None or self.text_encoder is None:
+                raise ValueError("no tokenizer/text_encoder attached: pass prompt_embeds / negative_prompt_embeds")
+            ids = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                 truncation=True, return_tensors="pt").input_ids
+            prompt_embeds = self.text_encoder(ids.to(device))[0]
+        prompt_embeds = prompt_embeds.to(device=device)
+        bs, n, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1).view(bs * num_images_per_prompt, n, -1)
+        if not do_cfg:
+            return prompt_embeds
+        if negative_prompt_embeds is None:
+            if self.tokenizer is None or self.text_encoder is None:
+                raise ValueError("no tokenizer/text_encoder attached: pass negative_prompt_embeds")
+            neg = [""] * bs if negative_prompt is None else ([negative_prompt] if isinstance(negative_prompt, str) else negative_prompt)
+            ids = self.tokenizer(neg, padding="max_length", max_length=n, truncation=True, return_tensors="pt").input_ids
+            negative_prompt_embeds = self.text_encoder(ids.to(device))[0]
+        negative_prompt_embeds = negative_prompt_embeds.to(device=device)
+        negative_prompt_embeds = negative_prompt_embeds.repeat(1, num_images_per_prompt, 1).view(bs * num_images_per_prompt, n, -1)
+        return torch.cat([negative_prompt_embeds, prompt_embeds])           # line 418: unconditional half first
+
+    def check_inputs(self, prompt, height, width, callback_steps, negative_prompt=None, prompt_embeds=None,
+                     negative_prompt_embeds=None):
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_steps is None or not isinstance(callback_steps, int) or callback_steps <= 0:
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one of the two.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but"
+                             f" got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` {negative_prompt_embeds.shape}.")
+
+    def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator,
+                        latents=None):
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
+            latents = latents.to(device=device, dtype=dtype)
+        return latents * self.scheduler.init_noise_sigma
+
+    def decode_latents(self, latents):
+        """pipeline_videogen.py:422-429 (stock PyTorch-ROCm VAE; outside the latents/s metric)."""
+        if self.vae is None:
+            raise ValueError("no vae attached: use output_type='latent'")
+        b, c, f, h, w = latents.shape
+        frames = (latents / 0.18215).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+        video = self.vae.decode(frames.to(next(self.vae.parameters()).dtype)).sample
+        video = video.reshape(b, f, *video.shape[1:]).permute(0, 1, 3, 4, 2)
+        return ((video / 2 + 0.5) * 255).add_(0.5).clamp_(0, 255).to(dtype=torch.uint8).cpu().contiguous()
+
+    # ------------------------------------------------------------------ the denoise loop (662-689)
+    @torch.no_grad()
+    def denoise(self, latents: torch.Tensor, ctx: torch.Tensor, num_inference_steps: int, guidance_scale: float,
+                generator=None, callback: Optional[Callable] = None, callback_steps: int = 1) -> torch.Tensor:
+        """latents fp32 [P, C, F, h, w] on the device, ctx fp16 [2P, n, d] = [negative | prompt] -> denoised fp32."""
+        dev = latents.device
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps)
+        timesteps = [int(t) for t in sch.timesteps]
+        do_cfg = guidance_scale > 1.0
+        if not do_cfg:
+            raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance) is outside the fused MI355X loop")
+        x = latents.to(torch.float32).contiguous().clone()
+        p = x.shape[0]
+        model_in = torch.empty((2 * p,) + tuple(x.shape[1:]), dtype=torch.float16, device=dev)
+        ops.latents_to_model_input(x, model_in)
+        self.unet.prepare(2 * p, x.shape[2], x.shape[3], x.shape[4], ctx.shape[1])
+
+        # per-step noise: drawn on the host only when the caller's generator lives there, then staged through
+        # two pinned slots on a side stream so that neither the device nor the host waits for the other
+        host_noise = generator is not None and not isinstance(generator, list) and generator.device.type == "cpu"
+        noise_dev = torch.empty_like(x)
+        if host_noise:
+            pinned = [torch.empty(x.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+            staged = [torch.empty_like(x) for _ in range(2)]
+            copy_done = [None, None]        # slot's H2D copy finished  -> host may refill the pinned slot
+            step_done = [None, None]        # slot's consumer finished  -> side stream may overwrite the device slot
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        t_dev = torch.tensor(timesteps, dtype=torch.float32, device=dev)
+
+        for i, t in enumerate(timesteps):
+            eps = self.unet(model_in, t_dev[i], encoder_hidden_states=ctx).sample      # line 670
+            coeffs = sch.coefficients(t)
+            noise = None
+            slot = i & 1
+            if t > 0:
+                if host_noise:
+                    if copy_done[slot] is not None:
+                        copy_done[slot].synchronize()
+                    torch.randn(x.shape, generator=generator, dtype=torch.float32, out=pinned[slot])
+                    if step_done[slot] is not None:
+                        self._copy_stream.wait_event(step_done[slot])
+                    with torch.cuda.stream(self._copy_stream):
+                        staged[slot].copy_(pinned[slot], non_blocking=True)
+                    copy_done[slot] = torch.cuda.Event()
+                    copy_done[slot].record(self._copy_stream)
+                    main.wait_event(copy_done[slot])
+                    noise = staged[slot]
+                else:
+                    noise = noise_dev.normal_(generator=generator) if generator is not None else noise_dev.normal_()
+            ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs)           # lines 679-683 fused
+            if host_noise and t > 0:
+                step_done[slot] = torch.cuda.Event()
+                step_done[slot].record(main)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, x)
+        return x
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str], None] = None, image_tensor=None, height: Optional[int] = None,
+                 width: Optional[int] = None, video_length: int = 16, num_inference_steps: int = 50,
+                 guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: Optional[int] = 1,
+                 eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 output_type: Optional[str] = "pil", return_dict: bool = True, callback=None, callback_steps: int = 1,
+                 cross_attention_kwargs=None):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None:
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        device = self.device
+        do_cfg = guidance_scale > 1.0
+        ctx = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds,
+                                  negative_prompt_embeds).to(torch.float16).contiguous()
+        latents = self.prepare_latents(batch_size * num_images_per_prompt, self.unet.config.in_channels, video_length,
+                                       height, width, torch.float32, device, generator, latents)
+        latents = self.denoise(latents, ctx, num_inference_steps, guidance_scale, generator, callback, callback_steps)
+        if output_type == "latent":
+            video = latents
+        else:
+            video = self.decode_latents(latents)
+        if not return_dict:
+            return (video,)
+        return StableDiffusionPipelineOutput(video=video)

@@ -156,19 +156,26 @@ def rotary(t: torch.Tensor, rot_dim: int = 32, theta: float = 10000.0) -> torch.
     return out
 
 
+def temporal_attention_core(q, k, v, bias, rot_dim: int = 32):
+    """TemporalAttention._attention (attention.py:634-667) on split heads.
+    q, k, v: [n, heads, f, dh]; bias: [heads, f, f] -> [n, heads, f, dh].  q is scaled BEFORE the
+    rotary embedding (640, 644-646); scores get the relative-position bias (650) and the
+    max-subtracted softmax (656-658)."""
+    q = rotary(q * (q.shape[-1] ** -0.5), rot_dim)
+    k = rotary(k, rot_dim)
+    score = q @ k.transpose(-1, -2) + bias
+    prob = torch.softmax(score - score.amax(dim=-1, keepdim=True), dim=-1)
+    return prob @ v
+
+
 def temporal_attention(sd: SD, p: str, x, cfg: UNetConfig):
-    """TemporalAttention.forward + _attention (attention.py:580-632, 634-667).
-    x: [b*d, f, c].  q scaled BEFORE rotary (640), rotary on q,k (644-646), +rel-pos bias (650),
-    max-subtracted softmax (656-658), to_out with bias."""
+    """TemporalAttention.forward (attention.py:580-632): x [b*d, f, c]; no-bias q/k/v, to_out with bias."""
     heads = cfg.heads
     q = split_heads(F.linear(x, sd[p + "to_q.weight"]), heads)
     k = split_heads(F.linear(x, sd[p + "to_k.weight"]), heads)
     v = split_heads(F.linear(x, sd[p + "to_v.weight"]), heads)
-    q = rotary(q * (q.shape[-1] ** -0.5), cfg.rotary_dim)
-    k = rotary(k, cfg.rotary_dim)
-    score = q @ k.transpose(-1, -2) + rel_pos_bias(sd, p, x.shape[1], cfg)
-    prob = torch.softmax(score - score.amax(dim=-1, keepdim=True), dim=-1)
-    return F.linear(merge_heads(prob @ v), sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+    o = temporal_attention_core(q, k, v, rel_pos_bias(sd, p, x.shape[1], cfg), cfg.rotary_dim)
+    return F.linear(merge_heads(o), sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
 
 
 def geglu_ff(sd: SD, p: str, x):

@@ -1,0 +1,270 @@
+"""-m gpu: every HIP operator through the C ABI against the fp32 CPU oracle."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import TOL_OP, f32, h16, q16, rel_l2, rows, unrows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from lavie_amd import ops as o
+    return o
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------ linear family
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1280, 960, 320), (154, 640, 768), (384, 1280, 1280),
+                                   (130, 192, 64), (2560, 320, 1280), (77, 128, 128)])
+def test_linear_bias_residual(ops, M, N, K):
+    g = gen(M + N + K)
+    a = q16(torch.randn(M, K, generator=g))
+    w = q16(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g)
+    r = q16(torch.randn(M, N, generator=g))
+    ref = a @ w.t() + b + r
+    got = ops.linear(h16(a), h16(w), bias=f32(b), residual=h16(r))
+    assert rel_l2(got, ref) < TOL_OP
+    got2 = ops.linear(h16(a), h16(w))
+    assert rel_l2(got2, a @ w.t()) < TOL_OP
+
+
+def test_linear_residual_in_place(ops):
+    g = gen(5)
+    a = q16(torch.randn(512, 320, generator=g))
+    w = q16(torch.randn(320, 320, generator=g) / 18)
+    x = q16(torch.randn(512, 320, generator=g))
+    xd = h16(x)
+    ops.linear(h16(a), h16(w), residual=xd, out=xd)
+    assert rel_l2(xd, a @ w.t() + x) < TOL_OP
+
+
+def test_linear_per_batch_bias(ops):
+    g = gen(6)
+    a = q16(torch.randn(4 * 96, 128, generator=g))
+    w = q16(torch.randn(320, 128, generator=g) / 11)
+    b2 = torch.randn(4, 320, generator=g)
+    ref = a @ w.t() + b2.repeat_interleave(96, dim=0)
+    got = ops.linear(h16(a), h16(w), bias2=f32(b2), rows_per_batch=96)
+    assert rel_l2(got, ref) < TOL_OP
+
+
+@pytest.mark.parametrize("M,C", [(256, 320), (200, 640)])
+def test_geglu(ops, M, C):
+    g = gen(C)
+    a = q16(torch.randn(M, C, generator=g))
+    w = q16(torch.randn(8 * C, C, generator=g) / math.sqrt(C))
+    b = q16(torch.randn(8 * C, generator=g) * 0.1)
+    h, gate = (a @ w.t() + b).chunk(2, dim=-1)
+    ref = h * F.gelu(gate)
+    wp, bp = ops.pack_geglu(h16(w), h16(b))
+    got = ops.linear(h16(a), wp, bias=bp, geglu=True)
+    assert got.shape == (M, 4 * C)
+    assert rel_l2(got, ref) < TOL_OP
+
+
+# ------------------------------------------------------------------ 3x3 convolution family
+def conv_ref(x, w, b, stride=1, ups=0):
+    if ups:
+        x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    return F.conv2d(x, w, b, stride=stride, padding=1)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,stride,ups", [(4, 64, 128, 8, 8, 1, 0), (3, 320, 320, 10, 16, 1, 0),
+                                                      (4, 128, 128, 8, 12, 2, 0), (2, 64, 64, 5, 7, 2, 0),
+                                                      (4, 128, 64, 4, 6, 1, 1), (2, 640, 320, 5, 8, 1, 0)])
+def test_conv3x3(ops, n, cin, cout, h, w, stride, ups):
+    g = gen(n * cin + cout + h)
+    x = q16(torch.randn(n, cin, h, w, generator=g))
+    wt = q16(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = torch.randn(cout, generator=g)
+    ref = conv_ref(x, wt, b, stride, ups)
+    y = ops.conv3x3(h16(rows(x)), ops.pack_conv3x3(h16(wt)), f32(b), n, h, w, stride=stride, ups=ups)
+    got = unrows(y.float().cpu(), n, ref.shape[2], ref.shape[3])
+    assert rel_l2(got, ref) < TOL_OP
+
+
+def test_conv3x3_concat_shortcut_temb(ops):
+    """conv over [x1 | x2] + fused 1x1 shortcut of raw [s1 | s2] + per-video bias (ResnetBlock3D conv2 / conv1)."""
+    g = gen(11)
+    n, h, w, c1, c2, cout = 4, 6, 8, 128, 64, 192
+    x1, x2 = q16(torch.randn(n, c1, h, w, generator=g)), q16(torch.randn(n, c2, h, w, generator=g))
+    s1, s2 = q16(torch.randn(n, 64, h, w, generator=g)), q16(torch.randn(n, 128, h, w, generator=g))
+    wt = q16(torch.randn(cout, c1 + c2, 3, 3, generator=g) / 40)
+    ws = q16(torch.randn(cout, 192, 1, 1, generator=g) / 14)
+    b = torch.randn(cout, generator=g)
+    b2 = torch.randn(2, cout, generator=g)                     # 2 videos x 2 frames
+    ref = F.conv2d(torch.cat([x1, x2], 1), wt, b, padding=1) + F.conv2d(torch.cat([s1, s2], 1), ws)
+    ref = ref + b2.repeat_interleave(2, dim=0)[:, :, None, None]
+    wp = ops.pack_conv3x3(h16(wt), h16(ws))
+    y = ops.conv3x3(h16(rows(x1)), wp, f32(b), n, h, w, x2=h16(rows(x2)), sc1=h16(rows(s1)), sc2=h16(rows(s2)),
+                    bias2=f32(b2), rows_per_batch=2 * h * w)
+    assert rel_l2(unrows(y.float().cpu(), n, h, w), ref) < TOL_OP
+
+
+def test_conv3x3_residual(ops):
+    g = gen(12)
+    n, h, w, c = 2, 8, 8, 64
+    x = q16(torch.randn(n, c, h, w, generator=g))
+    r = q16(torch.randn(n, c, h, w, generator=g))
+    wt = q16(torch.randn(c, c, 3, 3, generator=g) / 24)
+    b = torch.randn(c, generator=g)
+    y = ops.conv3x3(h16(rows(x)), ops.pack_conv3x3(h16(wt)), f32(b), n, h, w, residual=h16(rows(r)))
+    assert rel_l2(unrows(y.float().cpu(), n, h, w), F.conv2d(x, wt, b, padding=1) + r) < TOL_OP
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("b,c,f,h,w", [(2, 320, 4, 8, 8), (2, 256, 16, 4, 4), (1, 1280, 2, 5, 8), (2, 2560, 2, 2, 4)])
+def test_group_norm_video_domain(ops, b, c, f, h, w):
+    """5-D GroupNorm: statistics across frames (resnet.py:180) + SiLU."""
+    g = gen(c + f)
+    x = q16(torch.randn(b, c, f, h, w, generator=g) * torch.linspace(0.5, 2.0, f).reshape(1, 1, f, 1, 1) + 0.3)
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    ref = F.silu(F.group_norm(x, 32, gamma, beta, 1e-5))
+    xr = h16(x.permute(0, 2, 3, 4, 1).reshape(-1, c))
+    y = ops.group_norm(xr, f32(gamma), f32(beta), nb=b, groups=32, eps=1e-5, silu=True)
+    got = y.float().cpu().reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
+    assert rel_l2(got, ref) < TOL_OP
+
+
+def test_group_norm_frame_domain(ops):
+    """per-frame GroupNorm eps 1e-6, no activation (attention.py:324,369); must differ from the video domain."""
+    g = gen(21)
+    b, c, f, h, w = 2, 320, 4, 8, 8
+    x = q16(torch.randn(b, c, f, h, w, generator=g) * torch.linspace(0.5, 2.0, f).reshape(1, 1, f, 1, 1))
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    frames = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    ref = F.group_norm(frames, 32, gamma, beta, 1e-6)
+    y = ops.group_norm(h16(rows(frames)), f32(gamma), f32(beta), nb=b * f, groups=32, eps=1e-6, silu=False)
+    got = unrows(y.float().cpu(), b * f, h, w)
+    assert rel_l2(got, ref) < TOL_OP
+    wrong = F.group_norm(x, 32, gamma, beta, 1e-6).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    assert rel_l2(got, wrong) > 0.1
+
+
+def test_group_norm_concat_straddling_group(ops):
+    """[x1 | x2] with 1280 + 640 channels: 60 channels per group, group 21 straddles the two tensors."""
+    g = gen(22)
+    b, f, h, w, c1, c2 = 1, 2, 4, 4, 1280, 640
+    x1 = q16(torch.randn(b, c1, f, h, w, generator=g) + 0.5)
+    x2 = q16(torch.randn(b, c2, f, h, w, generator=g) * 2.0)
+    gamma, beta = 1 + 0.1 * torch.randn(c1 + c2, generator=g), 0.1 * torch.randn(c1 + c2, generator=g)
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], 1), 32, gamma, beta, 1e-5))
+    r1 = h16(x1.permute(0, 2, 3, 4, 1).reshape(-1, c1))
+    r2 = h16(x2.permute(0, 2, 3, 4, 1).reshape(-1, c2))
+    y = ops.group_norm(r1, f32(gamma), f32(beta), nb=b, groups=32, eps=1e-5, silu=True, x2=r2)
+    got = y.float().cpu().reshape(b, f, h, w, c1 + c2).permute(0, 4, 1, 2, 3)
+    assert rel_l2(got, ref) < TOL_OP
+
+
+@pytest.mark.parametrize("rows_,c", [(1000, 320), (333, 640), (64, 1280), (5, 256)])
+def test_layer_norm(ops, rows_, c):
+    g = gen(c)
+    x = q16(torch.randn(rows_, c, generator=g) * 2 + 0.7)
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    ref = F.layer_norm(x, (c,), gamma, beta, 1e-5)
+    assert rel_l2(ops.layer_norm(h16(x), f32(gamma), f32(beta)), ref) < TOL_OP
+
+
+# ------------------------------------------------------------------ attention cores
+def attn_ref(q, k, v, heads, kv_div=1):
+    nb, lq, c = q.shape
+    dh = c // heads
+    if kv_div > 1:
+        k, v = k.repeat_interleave(kv_div, dim=0), v.repeat_interleave(kv_div, dim=0)
+    qh = q.reshape(nb, lq, heads, dh).permute(0, 2, 1, 3)
+    kh = k.reshape(nb, -1, heads, dh).permute(0, 2, 1, 3)
+    vh = v.reshape(nb, -1, heads, dh).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * dh ** -0.5, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(nb, lq, c)
+
+
+@pytest.mark.parametrize("nb,l,c", [(3, 160, 1280), (2, 640, 640), (2, 200, 320), (4, 40, 1280), (2, 64, 320), (1, 300, 320)])
+def test_self_attention_fused_qkv(ops, nb, l, c):
+    g = gen(l + c)
+    qkv = q16(torch.randn(nb * l, 3 * c, generator=g))
+    q, k, v = (t.reshape(nb, l, c) for t in qkv.split(c, dim=1))
+    ref = attn_ref(q, k, v, 8).reshape(nb * l, c)
+    d = h16(qkv)
+    got = ops.attention(d[:, :c], d[:, c:2 * c], d[:, 2 * c:], nb=nb, lq=l, lk=l, heads=8)
+    assert rel_l2(got, ref) < TOL_OP
+
+
+def test_self_attention_sharp_softmax(ops):
+    """one dominant key per query, placed in a later tile: exercises the online-softmax rescale."""
+    g = gen(31)
+    nb, l, c = 1, 192, 320
+    q = torch.randn(nb, l, c, generator=g)
+    k = torch.randn(nb, l, c, generator=g)
+    k[:, 150] = q[:, 7] * 3.0                      # key 150 (third tile) matches query 7 strongly
+    v = torch.randn(nb, l, c, generator=g)
+    q, k, v = q16(q), q16(k), q16(v)
+    ref = attn_ref(q, k, v, 8).reshape(nb * l, c)
+    got = ops.attention(h16(q.reshape(-1, c)), h16(k.reshape(-1, c)), h16(v.reshape(-1, c)), nb=nb, lq=l, lk=l, heads=8)
+    assert rel_l2(got, ref) < TOL_OP
+
+
+@pytest.mark.parametrize("b,f,d,c", [(2, 4, 64, 320), (2, 16, 40, 1280), (1, 2, 130, 640)])
+def test_cross_attention_text(ops, b, f, d, c):
+    """77 text keys shared by the f frames of a video (attention.py:364,529-532)."""
+    g = gen(d + c)
+    q = q16(torch.randn(b * f, d, c, generator=g))
+    kv = q16(torch.randn(b, 77, 2 * c, generator=g))
+    ref = attn_ref(q, kv[..., :c], kv[..., c:], 8, kv_div=f).reshape(-1, c)
+    kvd = h16(kv.reshape(-1, 2 * c))
+    got = ops.attention(h16(q.reshape(-1, c)), kvd[:, :c], kvd[:, c:], nb=b * f, lq=d, lk=77, heads=8, kv_batch_div=f)
+    assert rel_l2(got, ref) < TOL_OP
+
+
+@pytest.mark.parametrize("b,f,d,c", [(2, 16, 24, 320), (1, 16, 10, 640), (2, 16, 5, 1280), (1, 4, 7, 320), (1, 13, 3, 256)])
+def test_temporal_attention(ops, b, f, d, c):
+    from oracle import unet_fp32 as O
+    g = gen(f * d + c)
+    heads, dh = 8, c // 8
+    qkv = q16(torch.randn(b * f * d, 3 * c, generator=g))
+    emb = q16(torch.randn(32, heads, generator=g))
+    table = O.rel_pos_bucket_table(f, 32, 32)
+    bias = emb[table].permute(2, 0, 1).contiguous()                       # [heads, f, f]
+    # oracle works on (b d) f c sequences: regroup the (b f d) token order
+    seq = qkv.reshape(b, f, d, 3, heads, dh).permute(3, 0, 2, 4, 1, 5).reshape(3, b * d, heads, f, dh)
+    ref = O.temporal_attention_core(seq[0], seq[1], seq[2], bias, 32)     # [(b d), heads, f, dh]
+    ref = ref.reshape(b, d, heads, f, dh).permute(0, 3, 1, 2, 4).reshape(b * f * d, c)
+    cos, sin = ops.rotary_tables(f, 32)
+    got = ops.temporal_attention(h16(qkv), b, f, d, heads, f32(bias), cos, sin)
+    assert rel_l2(got, ref) < TOL_OP
+
+
+def test_relpos_bias_matches_oracle_tables(ops):
+    from oracle import unet_fp32 as O
+    for f in (16, 61, 1, 9):
+        assert torch.equal(ops.relpos_buckets(f), O.rel_pos_bucket_table(f, 32, 32))
+
+
+# ------------------------------------------------------------------ CFG + DDPM step
+def test_cfg_ddpm_step(ops):
+    from oracle.ddpm import DDPMSchedule
+    from lavie_amd.scheduling_ddpm import DDPMScheduler
+    g = gen(41)
+    n = 4 * 16 * 8 * 8
+    eps = q16(torch.randn(2, n, generator=g))
+    x = torch.randn(n, generator=g)
+    noise = torch.randn(n, generator=g)
+    osch, sch = DDPMSchedule(), DDPMScheduler()
+    osch.set_timesteps(50)
+    sch.set_timesteps(50)
+    for t in (980, 500, 20, 0):
+        guided = eps[0] + 7.5 * (eps[1] - eps[0])
+        ref = osch.step(guided, t, x, noise if t > 0 else None)
+        xd = f32(x)
+        model_in = torch.empty(2, n, dtype=torch.float16, device="cuda")
+        ops.cfg_ddpm_step(h16(eps), xd, f32(noise) if t > 0 else None, model_in, 7.5, sch.coefficients(t))
+        assert rel_l2(xd, ref) < 1e-5
+        assert rel_l2(model_in[0], ref) < 1e-3 and torch.equal(model_in[0], model_in[1])
