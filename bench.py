@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: video-latents/sec of the LaVie base T2V denoising path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input = ONE fully denoised video
+latent [4,16,40,64] per GPU: 50 DDPM steps x (CFG UNet forward at batch 2 + fused CFG/DDPM update)
+(BASELINE.json configs[1]; reference loop pipeline_videogen.py:662-689).  Prompt-level data
+parallelism: every rank denoises its own prompts (weak scaling), weights are broadcast once from
+rank 0, finished latents are all-gathered inside the timed region.  Prints ONE JSON line on rank 0.
+
+Extra objects on that line:
+  roofline          dominant kernel class by device time (the implicit-GEMM 3x3 convolution): algorithmic
+                    FLOP per launch / average launch duration, both measured live with HIP events on the
+                    launch stream inside the timed region, against the 2.5 PFLOP/s dense fp16 MFMA peak
+  roofline_temporal the temporal-attention core (HBM-bound): algorithmic bytes 4*tokens*C*2 per launch / duration
+  kernel_breakdown  every kernel class, from one extra instrumented UNet forward after the timed region
+  cpu_baseline      the fp32 CPU oracle (kind "port") timed on this host's cores on a bounded sample
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FRAMES, LAT_H, LAT_W, CTX_LEN, CTX_DIM = 16, 40, 64, 77, 768
+DDPM_STEPS, GUIDANCE = 50, 7.5
+UNET_TFLOP = 16.219           # algorithmic TFLOP of one CFG forward at this config
+PEAK_MFMA_TFLOPS = 2500.0     # dense fp16, gfx950 (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+CLASS_NAMES = ["conv3x3_igemm", "linear_igemm", "attention", "temporal_attention", "group_norm", "layer_norm", "other"]
+
+
+def synth_inputs(idx, device):
+    """SURVEY.md §8d synthetic inputs for prompt `idx` (CPU generators: device independent)."""
+    g = torch.Generator().manual_seed(1000 + idx)
+    pe = torch.randn(1, CTX_LEN, CTX_DIM, generator=g)
+    ne = torch.randn(1, CTX_LEN, CTX_DIM, generator=g)
+    lat = torch.randn(1, 4, FRAMES, LAT_H, LAT_W, generator=torch.Generator().manual_seed(2000 + idx))
+    return pe.to(device), ne.to(device), lat.to(device)
+
+
+def profile_begin(lib, mask, max_events):
+    from lavie_amd import _lib
+    _lib.check(lib.lavie_profile_begin(mask, max_events), "lavie_profile_begin")
+
+
+def profile_end(lib):
+    from lavie_amd import _lib
+    n = 7
+    launches = (ctypes.c_longlong * n)()
+    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.lavie_profile_end(stream, launches, ms, fl, by), "lavie_profile_end")
+    return [dict(name=CLASS_NAMES[i], launches=int(launches[i]), ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(n)]
+
+
+def cpu_baseline(sd_fp32, sample_frames):
+    """Oracle (fp32, all host cores) on a bounded sample: ONE CFG UNet forward at batch 2 with `sample_frames`
+    of the 16 frames at the full 40x64 latent.  Every op except the (negligible, 0.1 %) temporal-attention core
+    is linear in the frame count, so one video-latent = 50 steps x (16 / sample_frames) x this time."""
+    from oracle import unet_fp32 as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, sample_frames, LAT_H, LAT_W, generator=g)
+    ctx = torch.randn(2, CTX_LEN, CTX_DIM, generator=g)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.unet_forward(sd_fp32, x, 500, ctx)
+    dt = time.perf_counter() - t0
+    per_video = dt * (FRAMES / sample_frames) * DDPM_STEPS
+    return {"value": 1.0 / per_video, "unit": "video-latents/s", "cores": torch.get_num_threads(), "kind": "port",
+            "seconds_sampled": dt,
+            "sample": f"one fp32 CFG UNet forward, batch 2, {sample_frames} of {FRAMES} frames at 40x64 latent "
+                      f"({dt:.1f} s), extrapolated x{FRAMES // sample_frames} frames x{DDPM_STEPS} DDPM steps",
+            "host_cpu_count": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed video-latents per GPU")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed video-latents per GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-sample-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline instrumentation")
+    ap.add_argument("--ddpm-steps", type=int, default=DDPM_STEPS, help=argparse.SUPPRESS)   # debugging only
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists); build with __graft_entry__.build() and run on the GPU box")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from lavie_amd import _lib, prompt_dp, spec, weights
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    from lavie_amd.scheduling_ddpm import DDPMScheduler
+    from lavie_amd.unet import UNet3DConditionModel
+    lib = _lib.load()
+
+    # ---- model: random-init weights of the full architecture (909 M parameters), rank 0 -> RCCL broadcast
+    shapes = spec.param_shapes()
+    t_setup = time.perf_counter()
+    sd32 = weights.synth_state_dict(shapes, args.seed) if rank == 0 else None
+    views = prompt_dp.broadcast_weights(shapes, sd32, device)
+    net = UNet3DConditionModel(sample_size=64, cross_attention_dim=CTX_DIM, init_weights=False)
+    for name, p in net.named_parameters():
+        p.data = views[name]
+    net.prepare(2, FRAMES, LAT_H, LAT_W, CTX_LEN)
+    pipe = VideoGenPipeline(unet=net, scheduler=DDPMScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear"))
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
+
+    n_videos = args.warmup + args.steps
+    inputs = [synth_inputs(rank + world * i, device) for i in range(n_videos)]
+    torch.cuda.synchronize()
+
+    def one_video(i):
+        pe, ne, lat = inputs[i]
+        gen = torch.Generator().manual_seed(3000 + rank + world * i)
+        return pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=LAT_H * 8, width=LAT_W * 8,
+                    video_length=FRAMES, num_inference_steps=args.ddpm_steps, guidance_scale=GUIDANCE, generator=gen,
+                    output_type="latent").video
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_video(i)
+    barrier()
+
+    use_prof = not args.no_profile
+    if use_prof:   # conv3x3 (dominant) + temporal attention only: ~63 event pairs per forward, negligible
+        profile_begin(lib, 0b1001, 2 * 64 * args.ddpm_steps * args.steps + 1024)
+    t0 = time.perf_counter()
+    outs = [one_video(args.warmup + i) for i in range(args.steps)]
+    local_lat = torch.cat(outs, dim=0).to(torch.float16)
+    gathered = prompt_dp.gather_latents(local_lat, [args.steps] * world)       # the only data-path collective
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timed = profile_end(lib) if use_prof else None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = all(bool(torch.isfinite(g).all()) for g in gathered)
+
+    total_videos = args.steps * world
+    result = {
+        "metric": "video-latents/sec (16f x 320x512, 50 DDPM steps)",
+        "value": total_videos / elapsed,
+        "unit": "video-latents/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: base T2V, one prompt per GPU at a time, 16x320x512 "
+                               "(latent 4x16x40x64), DDPM 50 steps, CFG 7.5 (UNet batch 2), fp16, random-init 909M-param UNet",
+                   "ddpm_steps": args.ddpm_steps, "guidance_scale": GUIDANCE, "latent": [4, FRAMES, LAT_H, LAT_W],
+                   "prompts_per_gpu": args.steps, "parallelism": f"prompt-dp{world}",
+                   "collectives": "1 weight broadcast (setup), 1 latent all_gather (timed)"},
+        "outputs_finite": finite,
+        "setup_seconds": setup_s,
+        "achieved_tflops_whole_path": UNET_TFLOP * args.ddpm_steps * total_videos / elapsed / world,
+        "mfma_fraction_whole_path": UNET_TFLOP * args.ddpm_steps * total_videos / elapsed / world / PEAK_MFMA_TFLOPS,
+    }
+
+    if rank == 0 and timed is not None:
+        conv, temp = timed[0], timed[3]
+        if conv["launches"]:
+            a = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "igemm_kernel<GATHER> (3x3 conv, implicit GEMM, MFMA 16x16x32 f16)",
+                                  "bound": "mfma", "achieved": a, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": a / PEAK_MFMA_TFLOPS, "traffic": None, "launches": conv["launches"],
+                                  "avg_launch_us": 1e3 * conv["ms"] / conv["launches"],
+                                  "flop_per_launch": conv["flops"] / conv["launches"]}
+        if temp["launches"]:
+            bw = temp["bytes"] / (temp["ms"] * 1e-3) / 1e9
+            result["roofline_temporal"] = {"kernel": "temporal_attention_kernel<1>", "bound": "hbm", "achieved": bw,
+                                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bw / PEAK_HBM_GBS,
+                                           "traffic": None, "launches": temp["launches"],
+                                           "avg_launch_us": 1e3 * temp["ms"] / temp["launches"],
+                                           "bytes_per_launch": temp["bytes"] / temp["launches"]}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # filled from rocprofv3 --pmc passes, see DESIGN.md
+        if os.path.isfile(pmc):
+            tr = json.load(open(pmc))
+            for key in ("roofline", "roofline_temporal"):
+                if key in result and key in tr:
+                    result[key]["traffic"] = tr[key]
+
+    # ---- full per-class breakdown: one extra instrumented forward, outside the timed region
+    if rank == 0 and use_prof:
+        pe, ne, lat = inputs[0]
+        ctx = torch.cat([ne, pe]).half().contiguous()
+        x2 = torch.cat([lat, lat]).half().contiguous()
+        net(x2, 500, encoder_hidden_states=ctx)
+        torch.cuda.synchronize()
+        profile_begin(lib, 0x7F, 4096)
+        t1 = time.perf_counter()
+        net(x2, 500, encoder_hidden_states=ctx)
+        rows = profile_end(lib)
+        fwd_ms = 1e3 * (time.perf_counter() - t1)
+        result["kernel_breakdown"] = {
+            "unet_forward_ms_instrumented": fwd_ms,
+            "classes": [dict(name=r["name"], launches=r["launches"], ms=round(r["ms"], 4),
+                             tflops=(r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 and r["flops"] > 0 else None),
+                             gbs=(r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else None)) for r in rows]}
+
+    if rank == 0 and world == 1 and args.cpu_sample_frames > 0:
+        result["cpu_baseline"] = cpu_baseline({k: v.float() for k, v in sd32.items()}, args.cpu_sample_frames)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

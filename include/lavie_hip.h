@@ -68,7 +68,9 @@ int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float
 /* GroupNorm (+ optional SiLU) over channels-last rows; the "batch" is whatever shares statistics:
  *   video domain  (resnet.py:180,191; unet.py:504): NB = b,   P = f*h*w   rows per batch
  *   frame domain  (attention.py:324,369)          : NB = b*f, P = h*w
- * Input may be the virtual concat [x1 | x2].  stats_ws: NB*groups*2 floats of scratch. */
+ * Input may be the virtual concat [x1 | x2].  stats_ws: lavie_group_norm_ws_floats(NB, groups) floats of
+ * scratch (slab partials + mean/rstd; no atomics: results are bit-reproducible). */
+long long lavie_group_norm_ws_floats(int NB, int groups);
 int lavie_group_norm_f16(const void* x1, int C1, const void* x2, int C2, int NB, int P, int groups, const float* gamma,
                          const float* beta, float eps, int silu, float* stats_ws, void* y, void* stream);
 
@@ -99,6 +101,17 @@ int lavie_relpos_buckets(int F, int num_buckets, int max_distance, int* out_host
 int lavie_cfg_ddpm_step(const void* eps2, float* x, const float* noise, void* model_in2, long long n, float guidance,
                         float k_x, float k_eps, float c_x0, float c_xt, float sigma, void* stream);
 int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hook: HIP-event timing per kernel class on the launch stream (bench.py's roofline leg).
+ * Classes: 0 conv3x3 (implicit GEMM, gathered), 1 linear/1x1/GEGLU GEMM, 2 spatial+text attention core,
+ * 3 temporal attention core, 4 GroupNorm, 5 LayerNorm, 6 other.  lavie_profile_end synchronises the
+ * stream and fills four host arrays of LAVIE_PROFILE_CLASSES entries (launches, milliseconds,
+ * algorithmic flops, algorithmic bytes — the per-launch figures are defined in DESIGN.md).
+ * ---------------------------------------------------------------------------------------------- */
+#define LAVIE_PROFILE_CLASSES 7
+int lavie_profile_begin(unsigned mask, int max_events);
+int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole denoiser: UNet3DConditionModel.forward (unet.py:366-512)

@@ -36,6 +36,7 @@ SIGNATURES = {
     "lavie_pack_geglu_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_int, c_void_p]),
     "lavie_group_norm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float_p, c_float_p, c_float,
                                       c_int, c_float_p, c_void_p, c_void_p]),
+    "lavie_group_norm_ws_floats": (c_ll, [c_int, c_int]),
     "lavie_layer_norm_f16": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "lavie_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_void_p]),
@@ -45,6 +46,9 @@ SIGNATURES = {
     "lavie_cfg_ddpm_step": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
                                      c_float, c_float, c_void_p]),
     "lavie_latents_to_model_input": (c_int, [c_float_p, c_void_p, c_ll, c_void_p]),
+    "lavie_profile_begin": (c_int, [C.c_uint, c_int]),
+    "lavie_profile_end": (c_int, [c_void_p, C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
     "lavie_unet_create": (c_int, [C.POINTER(UNetConfigC), C.POINTER(c_void_p)]),
     "lavie_unet_destroy": (c_int, [c_void_p]),
     "lavie_unet_num_params": (c_int, [c_void_p]),

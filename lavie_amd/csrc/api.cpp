@@ -4,6 +4,7 @@
 #include <new>
 
 #include "engine.h"
+#include "profile.h"
 
 using namespace lavie;
 
@@ -93,11 +94,10 @@ int lavie_group_norm_f16(const void* x1, int C1, const void* x2, int C2, int NB,
     LAVIE_CHECK(x1 && gamma && beta && stats_ws && y, "group_norm: null tensor");
     LAVIE_CHECK(NB > 0 && P > 0 && groups > 0, "group_norm: empty problem");
     if (!x2) C2 = 0;
-    LAVIE_HIP(hipMemsetAsync(stats_ws, 0, (size_t)NB * groups * 2 * sizeof(float), S(stream)));
-    int rc = launch_gn_stats(H(x1), C1, H(x2), C2, NB, P, groups, stats_ws, S(stream));
-    if (rc) return rc;
-    return launch_gn_apply(H(x1), C1, H(x2), C2, NB, P, groups, stats_ws, gamma, beta, eps, silu != 0, H(y), S(stream));
+    return launch_group_norm(H(x1), C1, H(x2), C2, NB, P, groups, gamma, beta, eps, silu != 0, stats_ws, H(y), S(stream));
 }
+
+long long lavie_group_norm_ws_floats(int NB, int groups) { return (long long)gn_workspace_floats(NB, groups); }
 
 int lavie_layer_norm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                          void* stream) {
@@ -140,6 +140,13 @@ int lavie_cfg_ddpm_step(const void* eps2, float* x, const float* noise, void* mo
 int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, void* stream) {
     LAVIE_CHECK(x && model_in2 && n > 0, "latents_to_model_input: bad arguments");
     return launch_f32_to_f16_dup2(x, H(model_in2), n, S(stream));
+}
+
+int lavie_profile_begin(unsigned mask, int max_events) { return profile_begin(mask, max_events); }
+
+int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host) {
+    LAVIE_CHECK(launches_host && ms_host && flops_host && bytes_host, "profile_end: null output");
+    return profile_end(S(stream), launches_host, ms_host, flops_host, bytes_host);
 }
 
 int lavie_unet_create(const lavie_unet_config* cfg, lavie_unet_t* out) {

@@ -18,6 +18,7 @@
 //    padded in LDS only — HBM traffic stays at the true head width.
 #include "common.h"
 #include "ops.h"
+#include "profile.h"
 
 namespace lavie {
 
@@ -245,6 +246,9 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
     LAVIE_CHECK(p.dh % 8 == 0 && p.dh >= 8 && p.dh <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", p.dh);
     LAVIE_CHECK(p.Lq > 0 && p.Lk > 0 && p.NBq > 0 && p.heads > 0 && p.kv_batch_div > 0, "attention: empty problem");
     LAVIE_CHECK(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must keep 16-B alignment");
+    const double tok_q = (double)p.NBq * p.Lq, width = (double)p.heads * p.dh;
+    ProfileScope prof(KC_ATTENTION, stream, 4.0 * tok_q * p.Lk * width,
+                      2.0 * (2.0 * tok_q * width + 2.0 * ((double)p.NBq / p.kv_batch_div) * p.Lk * width));
     const bool big = p.Lq > 64 * 3;     // >= 2 full 128-row blocks: use 32 rows per wave
     if (p.dh <= 64) return big ? launch_att<64, 2>(p, stream) : launch_att<64, 1>(p, stream);
     if (p.dh <= 96) return big ? launch_att<96, 2>(p, stream) : launch_att<96, 1>(p, stream);

@@ -419,8 +419,7 @@ struct FwdCtx {
     DeviceArena* ws;
     bool dry;               // plan only: allocate, launch nothing
     int B, F, ctx_len;
-    float* stats_pool;      // zeroed once per forward
-    size_t stats_off, stats_cap;
+    float* gn_ws;           // GroupNorm scratch, gn_workspace_floats(B*F, groups) floats
 };
 
 #define LAUNCH(expr)              \
@@ -432,12 +431,6 @@ struct FwdCtx {
     type* var = (type*)c.ws->alloc((size_t)(count) * sizeof(type));                                              \
     LAVIE_CHECK(var != nullptr, "workspace exhausted: call lavie_unet_prepare for this shape (needed %zu more B)", \
                 (size_t)(count) * sizeof(type))
-
-static float* take_stats(FwdCtx& c, size_t n) {
-    float* p = c.stats_pool + c.stats_off;
-    c.stats_off += n;
-    return c.stats_off <= c.stats_cap ? p : nullptr;
-}
 
 static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const float* bias, int N, int K, const half_t* R,
                   half_t* C, int ldc, int M, int epilogue = EPI_LINEAR) {
@@ -498,19 +491,14 @@ int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, cons
     WS(nrm, half_t, M * r.cin);
     WS(h1, half_t, M * r.cout);
     WS(n2, half_t, M * r.cout);
-    float* st1 = take_stats(c, (size_t)c.B * G * 2);
-    float* st2 = take_stats(c, (size_t)c.B * G * 2);
-    LAVIE_CHECK(st1 && st2, "resnet: statistics pool exhausted");
-    LAUNCH(launch_gn_stats(x1, C1, x2, C2, c.B, P, G, st1, c.s));
-    LAUNCH(launch_gn_apply(x1, C1, x2, C2, c.B, P, G, st1, r.n1.g, r.n1.b, cfg_.norm_eps, true, nrm, c.s));
+    LAUNCH(launch_group_norm(x1, C1, x2, C2, c.B, P, G, r.n1.g, r.n1.b, cfg_.norm_eps, true, c.gn_ws, nrm, c.s));
     {
         const half_t* src[1] = {nrm};
         const int srcC[1] = {r.cin};
         RUN(conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, r.w1, 9 * r.cin, r.b1, tproj, ld_tproj, P, nullptr, h1, NI, H, W,
                     r.cout, 1, 0, zero_page_));
     }
-    LAUNCH(launch_gn_stats(h1, r.cout, nullptr, 0, c.B, P, G, st2, c.s));
-    LAUNCH(launch_gn_apply(h1, r.cout, nullptr, 0, c.B, P, G, st2, r.n2.g, r.n2.b, cfg_.norm_eps, true, n2, c.s));
+    LAUNCH(launch_group_norm(h1, r.cout, nullptr, 0, c.B, P, G, r.n2.g, r.n2.b, cfg_.norm_eps, true, c.gn_ws, n2, c.s));
     {
         const half_t* src[1] = {n2};
         const int srcC[1] = {r.cout};
@@ -536,13 +524,10 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     WS(att, half_t, (size_t)T * C);
     WS(wide, half_t, (size_t)T * 4 * C);          // qkv [T,3C] / GEGLU output [T,4C] / q2 [T,C]
     WS(kv2, half_t, (size_t)c.B * c.ctx_len * 2 * C);
-    float* st = take_stats(c, (size_t)NI * G * 2);
-    LAVIE_CHECK(st, "transformer: statistics pool exhausted");
     const size_t ti = &t - transformers_.data();
 
     // per-frame GroupNorm (eps 1e-6) + 1x1 proj_in (attention.py:369-373)
-    LAUNCH(launch_gn_stats(x, C, nullptr, 0, NI, D, G, st, c.s));
-    LAUNCH(launch_gn_apply(x, C, nullptr, 0, NI, D, G, st, t.gn.g, t.gn.b, 1e-6f, false, ln, c.s));
+    LAUNCH(launch_group_norm(x, C, nullptr, 0, NI, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s));
     RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, T));
 
     // spatial self-attention (attention.py:513-522)
@@ -605,13 +590,10 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
     const int temb = C0 * 4;
     const int G = cfg.norm_groups;
 
-    // statistics pool: every GroupNorm instance gets its own zeroed slot, one memset per forward
-    c.stats_cap = (size_t)(resnets_.size() * 2 + 1) * c.B * G * 2 + transformers_.size() * (size_t)NI * G * 2;
+    // GroupNorm scratch (partials + mean/rstd), shared by every GroupNorm of the pass: stream order keeps it safe
     {
-        WS(pool, float, c.stats_cap);
-        c.stats_pool = pool;
-        c.stats_off = 0;
-        if (!c.dry) LAVIE_HIP(hipMemsetAsync(pool, 0, c.stats_cap * sizeof(float), c.s));
+        WS(gnws, float, gn_workspace_floats(NI, G));
+        c.gn_ws = gnws;
     }
 
     // time embedding (unet.py:428-434) and all 22 resnet projections in one GEMV (resnet.py:186)
@@ -689,12 +671,9 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
     }
     // conv_norm_out + SiLU + conv_out (unet.py:504-506), back to the caller's NCFHW layout
     {
-        float* st = take_stats(c, (size_t)c.B * G * 2);
-        LAVIE_CHECK(st, "statistics pool exhausted");
         WS(nrm, half_t, rows(0) * C0);
         const int P = c.F * Hs[0] * Ws[0];
-        LAUNCH(launch_gn_stats(x, C0, nullptr, 0, c.B, P, G, st, c.s));
-        LAUNCH(launch_gn_apply(x, C0, nullptr, 0, c.B, P, G, st, norm_out_.g, norm_out_.b, cfg.norm_eps, true, nrm, c.s));
+        LAUNCH(launch_group_norm(x, C0, nullptr, 0, c.B, P, G, norm_out_.g, norm_out_.b, cfg.norm_eps, true, c.gn_ws, nrm, c.s));
         LAUNCH(launch_conv_out(nrm, conv_out_w_, conv_out_b_, out, c.B, C0, c.F, Hs[0], Ws[0], cfg.out_channels, c.s));
     }
     return 0;
@@ -714,7 +693,7 @@ int UNet::prepare(int B, int F, int H, int W, int ctx_len) {
     RUN(check_shape(cfg_, B, F, H, W, ctx_len));
     DeviceArena plan;
     plan.init_virtual();
-    FwdCtx c{nullptr, &plan, true, B, F, ctx_len, nullptr, 0, 0};
+    FwdCtx c{nullptr, &plan, true, B, F, ctx_len, nullptr};
     prep_H_ = H; prep_W_ = W;
     RUN(run(c, nullptr, nullptr, nullptr, nullptr));
     const size_t need = plan.peak() + (1 << 20);
@@ -731,7 +710,7 @@ int UNet::forward(const half_t* sample, const float* timesteps, const half_t* ct
     LAVIE_CHECK(ws_.total_bytes() > 0, "forward: call lavie_unet_prepare first");
     RUN(ensure_tables(F, stream));
     ws_.release(0);
-    FwdCtx c{stream, &ws_, false, B, F, ctx_len, nullptr, 0, 0};
+    FwdCtx c{stream, &ws_, false, B, F, ctx_len, nullptr};
     prep_H_ = H; prep_W_ = W;
     return run(c, sample, timesteps, ctx, out);
 }
@@ -746,10 +725,8 @@ int UNet::resnet_forward(const char* prefix, const half_t* x1, int C1, const hal
     DeviceArena local;
     const size_t M = (size_t)B * F * H * W;
     RUN(local.init_fixed((M * (r->cin + 2 * r->cout)) * sizeof(half_t) + (size_t)B * r->cout * 4 + (4 << 20)));
-    FwdCtx c{stream, &local, false, B, F, 0, nullptr, 0, 0};
-    c.stats_cap = (size_t)2 * B * cfg_.norm_groups * 2;
-    c.stats_pool = (float*)local.alloc(c.stats_cap * sizeof(float));
-    LAVIE_HIP(hipMemsetAsync(c.stats_pool, 0, c.stats_cap * sizeof(float), stream));
+    FwdCtx c{stream, &local, false, B, F, 0, nullptr};
+    c.gn_ws = (float*)local.alloc(gn_workspace_floats(B * F, cfg_.norm_groups) * sizeof(float));
     float* tproj = (float*)local.alloc((size_t)B * r->cout * sizeof(float));
     RUN(launch_gemv(temb, tproj_.w + (size_t)r->temb_off * tproj_.K, tproj_.b + r->temb_off, tproj, B, r->cout, tproj_.K, 1, 0, stream));
     RUN(run_resnet(c, *r, x1, C1, C2 ? x2 : nullptr, C2, tproj, r->cout, y, H, W));
@@ -768,10 +745,8 @@ int UNet::transformer_forward(const char* prefix, half_t* x, const half_t* ctx, 
     DeviceArena local;
     const size_t T = (size_t)B * F * H * W;
     RUN(local.init_fixed(T * t->C * 7 * sizeof(half_t) + (size_t)B * ctx_len * 2 * t->C * sizeof(half_t) + (4 << 20)));
-    FwdCtx c{stream, &local, false, B, F, ctx_len, nullptr, 0, 0};
-    c.stats_cap = (size_t)B * F * cfg_.norm_groups * 2;
-    c.stats_pool = (float*)local.alloc(c.stats_cap * sizeof(float));
-    LAVIE_HIP(hipMemsetAsync(c.stats_pool, 0, c.stats_cap * sizeof(float), stream));
+    FwdCtx c{stream, &local, false, B, F, ctx_len, nullptr};
+    c.gn_ws = (float*)local.alloc(gn_workspace_floats(B * F, cfg_.norm_groups) * sizeof(float));
     RUN(run_transformer(c, *t, x, ctx, H, W));
     LAVIE_HIP(hipStreamSynchronize(stream));
     return 0;

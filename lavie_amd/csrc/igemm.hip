@@ -20,6 +20,7 @@
 //  * Out-of-image taps read a 128-B zero page instead of branching.
 //  * blockIdx is remapped so that consecutive tiles (which share activation rows) share an XCD L2.
 #include "igemm.h"
+#include "profile.h"
 
 namespace lavie {
 
@@ -224,6 +225,10 @@ static int launch_tile(const IgemmParams& p, hipStream_t stream) {
 
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream) {
     LAVIE_CHECK(p.M > 0 && p.N > 0 && p.nk > 0, "igemm: empty problem M=%d N=%d nk=%d", p.M, p.N, p.nk);
+    const double K = (double)p.nk * IGEMM_BK;
+    // algorithmic work: 2 M N K flops; bytes = every operand element once (A incl. im2col reuse counted once)
+    ProfileScope prof(gather ? KC_CONV3X3 : KC_LINEAR, stream, 2.0 * p.M * p.N * K,
+                      2.0 * ((double)p.M * K / (gather ? 9.0 : 1.0) + (double)p.N * K + (double)p.M * p.N));
     LAVIE_CHECK(p.N % 4 == 0 && p.ldc % 4 == 0, "igemm: N and ldc must be multiples of 4");
     if (epilogue == EPI_GEGLU) {
         LAVIE_CHECK(p.N % 128 == 0, "igemm: GEGLU needs N %% 128 == 0 (N=%d)", p.N);

@@ -13,11 +13,13 @@
 // All three are HBM-bound: 16-byte vector accesses, fp32 statistics, wave/LDS reductions.
 #include "common.h"
 #include "ops.h"
+#include "profile.h"
 
 namespace lavie {
 
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_C = 4096;
+constexpr int GN_MAX_SLABS = 2048;  // NB * slabs of the statistics pass (one finalize wave folds <= 512 partials)
 
 struct GnGeom {
     int nvec;   // (C1 + C2) / 8
@@ -42,20 +44,18 @@ __device__ __forceinline__ const half_t* gn_src(const half_t* x1, int C1, const 
     return c < C1 ? x1 + row * C1 + c : x2 + row * C2 + (c - C1);
 }
 
-// stats[nb][g][0..1] += (sum, sum of squares) of this block's slab.  `stats` must be zero on entry.
+// Pass 1: per-slab partial (sum, sum of squares) of every group -> partials[(nb*slabs + slab)*groups + g].
+// No atomics anywhere: fixed summation order, so a forward pass is bit-reproducible.
 template <int VPT>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const half_t* __restrict__ x1, int C1,
                                                              const half_t* __restrict__ x2, int C2, int P,
                                                              int rows_per_slab, int groups, int tx, int ty,
-                                                             float* __restrict__ stats) {
-    __shared__ float s_sum[GN_MAX_C];
-    __shared__ float s_sq[GN_MAX_C];
+                                                             float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char gn_smem[];
+    float* s_part = reinterpret_cast<float*>(gn_smem);          // [ty][ctot][2]
     const int ctot = C1 + C2;
     const int nb = blockIdx.y;
     const int tid = threadIdx.x;
-    for (int c = tid; c < ctot; c += GN_THREADS) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-    __syncthreads();
-
     const int vx = tid % tx, vy = tid / tx;
     const int r0 = blockIdx.x * rows_per_slab;
     const int r1 = min(P, r0 + rows_per_slab);
@@ -79,17 +79,45 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const half_t* __re
         for (int v = 0; v < VPT; ++v) {
             const int c = (vx + v * tx) * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { atomicAdd(&s_sum[c + j], s[v][j]); atomicAdd(&s_sq[c + j], q[v][j]); }
+            for (int j = 0; j < 8; ++j) {
+                s_part[((size_t)vy * ctot + c + j) * 2] = s[v][j];
+                s_part[((size_t)vy * ctot + c + j) * 2 + 1] = q[v][j];
+            }
         }
     }
     __syncthreads();
     const int cpg = ctot / groups;
     for (int g = tid; g < groups; g += GN_THREADS) {
         float a = 0.f, b = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += s_sum[c]; b += s_sq[c]; }
-        float* dst = stats + ((size_t)nb * groups + g) * 2;
-        atomicAdd(dst, a);
-        atomicAdd(dst + 1, b);
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+            for (int y = 0; y < ty; ++y) { a += s_part[((size_t)y * ctot + c) * 2]; b += s_part[((size_t)y * ctot + c) * 2 + 1]; }
+        float* dst = partials + (((size_t)nb * gridDim.x + blockIdx.x) * groups + g) * 2;
+        dst[0] = a;
+        dst[1] = b;
+    }
+}
+
+// Pass 2: one wave per (batch, group): fold the slab partials in a fixed order -> (mean, rstd).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int slabs, int groups,
+                                                         int total, float inv_count, float eps,
+                                                         float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);        // nb * groups + g
+    if (idx >= total) return;
+    const int nb = idx / groups, g = idx - nb * groups;
+    float a = 0.f, b = 0.f;
+    for (int sl = lane; sl < slabs; sl += 64) {
+        const float* src = partials + (((size_t)nb * slabs + sl) * groups + g) * 2;
+        a += src[0];
+        b += src[1];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+        const float mean = a * inv_count;
+        const float var = fmaxf(b * inv_count - mean * mean, 0.f);
+        stats[(size_t)idx * 2] = mean;
+        stats[(size_t)idx * 2 + 1] = rsqrtf(var + eps);
     }
 }
 
@@ -100,7 +128,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
                                                              int rows_per_slab, int groups, int tx, int ty,
                                                              const float* __restrict__ stats,
                                                              const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float eps,
+                                                             const float* __restrict__ beta,
                                                              half_t* __restrict__ y) {
     __shared__ float s_a[GN_MAX_C];
     __shared__ float s_b[GN_MAX_C];
@@ -108,14 +136,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
     const int cpg = ctot / groups;
     const int nb = blockIdx.y;
     const int tid = threadIdx.x;
-    const float inv_count = 1.0f / ((float)P * (float)cpg);
     for (int c = tid; c < ctot; c += GN_THREADS) {
         const float* st = stats + ((size_t)nb * groups + c / cpg) * 2;
-        const float mean = st[0] * inv_count;
-        const float var = fmaxf(st[1] * inv_count - mean * mean, 0.f);
-        const float a = rsqrtf(var + eps) * gamma[c];
+        const float a = st[1] * gamma[c];
         s_a[c] = a;
-        s_b[c] = beta[c] - mean * a;
+        s_b[c] = beta[c] - st[0] * a;
     }
     __syncthreads();
     const int vx = tid % tx, vy = tid / tx;
@@ -140,26 +165,33 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
     }
 }
 
-static int gn_slabs(int P, int NB, int ty, int* rows_per_slab) {
+static int gn_slabs(int P, int NB, int ty, int cap_total, int* rows_per_slab) {
     int slabs = cdiv(P, ty * 4);                 // at least 4 rows per row-lane
-    const int cap = NB >= 2048 ? 1 : 2048 / NB;  // ~2k blocks fill 256 CUs x 8
+    const int cap = NB >= cap_total ? 1 : cap_total / NB;
     if (slabs > cap) slabs = cap;
     if (slabs < 1) slabs = 1;
     *rows_per_slab = cdiv(P, slabs);
     return cdiv(P, *rows_per_slab);
 }
 
-int launch_gn_stats(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, float* stats,
-                    hipStream_t stream) {
+size_t gn_workspace_floats(int NB, int groups) { return ((size_t)GN_MAX_SLABS + NB) * groups * 2 + (size_t)NB * groups * 2; }
+
+// stats_ws layout: [NB*groups*2 (mean, rstd)] [partials: NB*slabs*groups*2]
+int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* gamma,
+                      const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream) {
     GnGeom g;
     const int ctot = C1 + C2;
     LAVIE_CHECK(gn_geometry(ctot, &g), "group_norm: unsupported channel count %d", ctot);
     LAVIE_CHECK(C1 % 8 == 0 && C2 % 8 == 0 && ctot % groups == 0 && groups <= GN_THREADS, "group_norm: bad channels/groups");
+    ProfileScope prof(KC_GROUPNORM, stream, 0.0, 2.0 * 3.0 * (double)NB * P * ctot);   // read, read, write
+    float* stats = ws;
+    float* partials = ws + (size_t)NB * groups * 2;
     int rps;
-    const int slabs = gn_slabs(P, NB, g.ty, &rps);
+    const int slabs = gn_slabs(P, NB, g.ty, GN_MAX_SLABS, &rps);      // NB * slabs <= GN_MAX_SLABS + NB
+    const size_t lds = (size_t)g.ty * ctot * 2 * sizeof(float);
     dim3 grid(slabs, NB);
 #define LAVIE_GN_STATS(V) \
-    hipLaunchKernelGGL(gn_stats_kernel<V>, grid, dim3(GN_THREADS), 0, stream, x1, C1, x2, C2, P, rps, groups, g.tx, g.ty, stats)
+    hipLaunchKernelGGL(gn_stats_kernel<V>, grid, dim3(GN_THREADS), lds, stream, x1, C1, x2, C2, P, rps, groups, g.tx, g.ty, partials)
     switch (g.vpt) {
         case 1: LAVIE_GN_STATS(1); break;
         case 2: LAVIE_GN_STATS(2); break;
@@ -168,21 +200,16 @@ int launch_gn_stats(const half_t* x1, int C1, const half_t* x2, int C2, int NB, 
     }
 #undef LAVIE_GN_STATS
     LAVIE_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_gn_apply(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* stats,
-                    const float* gamma, const float* beta, float eps, bool silu, half_t* y, hipStream_t stream) {
-    GnGeom g;
-    const int ctot = C1 + C2;
-    LAVIE_CHECK(gn_geometry(ctot, &g), "group_norm: unsupported channel count %d", ctot);
-    LAVIE_CHECK(C1 % 8 == 0 && C2 % 8 == 0 && ctot % groups == 0, "group_norm: bad channels/groups");
-    int rps;
-    const int slabs = gn_slabs(P, NB, g.ty, &rps);
-    dim3 grid(slabs, NB);
-#define LAVIE_GN_APPLY(V, S)                                                                                      \
-    hipLaunchKernelGGL((gn_apply_kernel<V, S>), grid, dim3(GN_THREADS), 0, stream, x1, C1, x2, C2, P, rps, groups, \
-                       g.tx, g.ty, stats, gamma, beta, eps, y)
+    const int total = NB * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(total, 4)), dim3(256), 0, stream, partials, slabs, groups, total,
+                       1.0f / ((float)P * (float)(ctot / groups)), eps, stats);
+    LAVIE_HIP(hipGetLastError());
+    int rps2;
+    const int slabs2 = gn_slabs(P, NB, g.ty, 2048, &rps2);
+    dim3 grid2(slabs2, NB);
+#define LAVIE_GN_APPLY(V, S)                                                                                        \
+    hipLaunchKernelGGL((gn_apply_kernel<V, S>), grid2, dim3(GN_THREADS), 0, stream, x1, C1, x2, C2, P, rps2, groups, \
+                       g.tx, g.ty, stats, gamma, beta, y)
 #define LAVIE_GN_APPLY_V(V) \
     if (silu) LAVIE_GN_APPLY(V, true); else LAVIE_GN_APPLY(V, false)
     switch (g.vpt) {
@@ -253,6 +280,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* y, int rows, int C, float eps,
                      hipStream_t stream) {
     LAVIE_CHECK(C % 8 == 0 && C <= LN_MAX_VEC * 64 * 8, "layer_norm: unsupported width %d", C);
+    ProfileScope prof(KC_LAYERNORM, stream, 0.0, 2.0 * 2.0 * (double)rows * C);
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, gamma, beta, y, rows, C, eps);
     LAVIE_HIP(hipGetLastError());
     return 0;

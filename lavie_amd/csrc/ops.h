@@ -8,10 +8,11 @@
 namespace lavie {
 
 // ---- norm.hip
-int launch_gn_stats(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, float* stats,
-                    hipStream_t stream);
-int launch_gn_apply(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* stats,
-                    const float* gamma, const float* beta, float eps, bool silu, half_t* y, hipStream_t stream);
+// GroupNorm (+SiLU): statistics pass (per-slab partials), finalize (mean, rstd), apply.  `ws` is
+// gn_workspace_floats(NB, groups) floats of scratch, reusable by the next call on the same stream.
+size_t gn_workspace_floats(int NB, int groups);
+int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* gamma,
+                      const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream);
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* y, int rows, int C, float eps,
                      hipStream_t stream);
 

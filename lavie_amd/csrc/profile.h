@@ -1,0 +1,32 @@
+// Optional per-kernel-class timing with HIP events on the launch stream (used by bench.py to report
+// roofline.achieved live).  Disabled by default: launchers pay one branch.
+#pragma once
+#include "common.h"
+
+namespace lavie {
+
+enum KernelClass {
+    KC_CONV3X3 = 0,     // igemm, gathered A operand (3x3 convs incl. fused shortcut / concat / up / down sampling)
+    KC_LINEAR = 1,      // igemm, plain A rows (Linear, 1x1 conv, GEGLU)
+    KC_ATTENTION = 2,   // fused spatial / text attention core
+    KC_TEMPORAL = 3,    // temporal attention core
+    KC_GROUPNORM = 4,
+    KC_LAYERNORM = 5,
+    KC_OTHER = 6,
+    KC_COUNT = 7
+};
+
+struct ProfileScope {
+    ProfileScope(int cls, hipStream_t s, double flops, double bytes);
+    ~ProfileScope();
+    int slot;
+    hipStream_t stream;
+};
+
+// mask: bit i enables class i.  Returns 0.
+int profile_begin(unsigned mask, int max_events);
+// Synchronises `stream`, folds the recorded events; fills per class: launches, total ms, algorithmic flops, bytes.
+int profile_end(hipStream_t stream, long long* launches, double* ms, double* flops, double* bytes);
+bool profile_enabled(int cls);
+
+}  // namespace lavie

@@ -20,6 +20,7 @@
 // Algorithmic HBM bytes per launch: 4 * tokens * C * 2 (q, k, v read + o write).
 #include "common.h"
 #include "ops.h"
+#include "profile.h"
 
 namespace lavie {
 
@@ -223,6 +224,9 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
     LAVIE_CHECK(p.dh % 8 == 0 && p.dh <= 160 && p.rot_dim <= 32 && p.rot_dim <= p.dh && p.rot_dim % 2 == 0,
                 "temporal attention: dh=%d rot_dim=%d unsupported", p.dh, p.rot_dim);
     LAVIE_CHECK(p.ld % 8 == 0 && p.ldo % 8 == 0, "temporal attention: row strides must be multiples of 8 halfs");
+    const double tok = (double)p.B * p.F * p.D, width = (double)p.heads * p.dh;
+    // algorithmic bytes: q, k, v read + o written once: 4 * tokens * C * 2 B
+    ProfileScope prof(KC_TEMPORAL, stream, 4.0 * tok * p.F * width, 4.0 * tok * width * 2.0);
     const int NT = cdiv(p.F, 16) <= 1 ? 1 : 4;
     const int FP = NT * 16;
     // pick (HG, PT): largest tile whose three LDS arrays stay under ~64 KiB (2 workgroups per CU)

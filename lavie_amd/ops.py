@@ -120,7 +120,7 @@ def group_norm(x1, gamma, beta, nb, groups, eps, silu, x2=None):
     rows = x1.shape[0]
     c1, c2 = x1.shape[1], 0 if x2 is None else x2.shape[1]
     y = torch.empty(rows, c1 + c2, dtype=torch.float16, device=x1.device)
-    ws = torch.empty(nb * groups * 2, dtype=torch.float32, device=x1.device)
+    ws = torch.empty(_lib.load().lavie_group_norm_ws_floats(nb, groups), dtype=torch.float32, device=x1.device)
     _lib.check(_lib.load().lavie_group_norm_f16(_p(x1), c1, _p(x2), c2, nb, rows // nb, groups, _p(gamma), _p(beta),
                                                 float(eps), int(silu), _p(ws), _p(y), _stream()), "lavie_group_norm_f16")
     return y
@@ -193,3 +193,27 @@ def latents_to_model_input(x, model_in2):
     _chk32(x)
     _chk16(model_in2)
     _lib.check(_lib.load().lavie_latents_to_model_input(_p(x), _p(model_in2), x.numel(), _stream()))
+
+
+# ------------------------------------------------------------------ engine seams (sub-module forwards)
+def unet_resnet_block(net, prefix: str, x1, x2, temb, b: int, f: int, h: int, w: int):
+    """ResnetBlock3D.forward of `net`'s block `prefix` on channels-last rows (x2 = skip half or None).
+    temb: fp32 [b, time_embed_dim] — the output of time_embedding (the block applies SiLU + its projection)."""
+    _chk16(x1, x2)
+    _chk32(temb)
+    handle = net.engine_handle()
+    cout = dict(net.named_parameters())[prefix + ".conv2.bias"].shape[0]
+    y = torch.empty(x1.shape[0], cout, dtype=torch.float16, device=x1.device)
+    _lib.check(_lib.load().lavie_unet_resnet_forward(handle, prefix.encode(), _p(x1), x1.shape[1], _p(x2),
+                                                     0 if x2 is None else x2.shape[1], _p(temb), _p(y), b, f, h, w,
+                                                     _stream()), "lavie_unet_resnet_forward")
+    return y
+
+
+def unet_transformer(net, prefix: str, x, ctx, b: int, f: int, h: int, w: int):
+    """Transformer3DModel.forward of `net`'s block `prefix`; x rows are updated in place and returned."""
+    _chk16(x, ctx)
+    handle = net.engine_handle()
+    _lib.check(_lib.load().lavie_unet_transformer_forward(handle, prefix.encode(), _p(x), _p(ctx), b, f, h, w,
+                                                          ctx.shape[1], _stream()), "lavie_unet_transformer_forward")
+    return x

@@ -1,0 +1,160 @@
+"""CPU: host-side logic — parameter spec, weight recipe, scheduler arithmetic, library symbols, layout rules."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+import torch
+
+from lavie_amd import _lib, spec, weights
+from lavie_amd.config import BASE_CONFIG, UNetConfig
+from lavie_amd.scheduling_ddpm import DDPMScheduler
+from oracle import unet_fp32 as O
+from oracle.ddpm import DDPMSchedule
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spec_matches_oracle_inventory():
+    assert spec.param_shapes() == O.param_shapes()
+    assert len(spec.param_shapes()) == 830
+    small = UNetConfig(block_out_channels=(256, 512), attn_levels=(True, False), cross_attention_dim=128)
+    assert spec.param_shapes(small) == O.param_shapes(O.UNetConfig(block_out_channels=(256, 512), attn_levels=(True, False),
+                                                                   cross_attention_dim=128))
+
+
+def test_weight_recipe_is_order_and_subset_independent():
+    cfg = UNetConfig(block_out_channels=(64, 64), attn_levels=(False, False), cross_attention_dim=64)
+    shapes = spec.param_shapes(cfg)
+    full = weights.synth_state_dict(shapes, seed=5)
+    part = weights.synth_state_dict(shapes, seed=5, only_prefix="mid_block.")
+    assert part and all(torch.equal(full[k], v) for k, v in part.items())
+    again = weights.synth_state_dict(dict(reversed(list(shapes.items()))), seed=5)
+    assert all(torch.equal(full[k], again[k]) for k in full)
+    assert not torch.equal(full["conv_in.weight"], weights.synth_state_dict(shapes, seed=6)["conv_in.weight"])
+
+
+def test_temporal_out_projection_is_not_zero_in_synth_weights():
+    shapes = {k: v for k, v in spec.param_shapes().items() if k.endswith("attn_temp.to_out.0.weight")}
+    sd = weights.synth_state_dict(shapes, 0)
+    assert all(v.abs().max() > 0 for v in sd.values())
+
+
+def test_config_validation():
+    BASE_CONFIG.validate()
+    with pytest.raises(ValueError):
+        UNetConfig(block_out_channels=(100, 200), attn_levels=(True, False)).validate()
+    with pytest.raises(ValueError):
+        UNetConfig(block_out_channels=(128, 128), attn_levels=(True, False)).validate()      # head dim 16 < rotary 32
+
+
+def test_scheduler_matches_oracle_and_timesteps():
+    sch, osch = DDPMScheduler(), DDPMSchedule()
+    sch.set_timesteps(50)
+    osch.set_timesteps(50)
+    assert [int(t) for t in sch.timesteps] == osch.timesteps == list(range(980, -1, -20))
+    for t in osch.timesteps:
+        assert sch.coefficients(t) == pytest.approx(osch.coefficients(t), rel=1e-7)
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    x, eps = torch.randn(1, 4, 2, 4, 4), torch.randn(1, 4, 2, 4, 4)
+    got = sch.step(eps, 500, x, generator=g1).prev_sample
+    ref = osch.step(eps, 500, x, torch.randn(x.shape, generator=g2))
+    assert torch.allclose(got, ref, atol=1e-6)
+    assert torch.equal(sch.step(eps, 0, x).prev_sample, osch.step(eps, 0, x, None))          # no noise at t = 0
+
+
+def test_ddpm_posterior_matches_independent_closed_form():
+    """Cross-check against the textbook q(x_{t-1} | x_t, x_0) posterior for a respaced schedule — the form the
+    reference's in-tree OpenAI sampler uses (interpolation/diffusion/gaussian_diffusion.py:232-252, 362-394):
+    coef1 = beta_t sqrt(abar_prev) / (1 - abar_t), coef2 = (1 - abar_prev) sqrt(alpha_t) / (1 - abar_t)."""
+    sch = DDPMScheduler()
+    sch.set_timesteps(50)
+    ab = sch.alphas_cumprod.double()
+    for t in (980, 500, 20):
+        a_t, a_p = ab[t].item(), ab[t - 20].item()
+        beta = 1 - a_t / a_p
+        coef1 = beta * math.sqrt(a_p) / (1 - a_t)
+        coef2 = (1 - a_p) * math.sqrt(1 - beta) / (1 - a_t)
+        var = beta * (1 - a_p) / (1 - a_t)
+        k_x, k_e, c_x0, c_xt, sigma = sch.coefficients(t)
+        assert (c_x0, c_xt, sigma) == pytest.approx((coef1, coef2, math.sqrt(var)), rel=1e-5)
+        assert (k_x, k_e) == pytest.approx((1 / math.sqrt(a_t), math.sqrt(1 / a_t - 1)), rel=1e-5)
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports exactly what include/lavie_hip.h declares."""
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "lavie_hip.h")).read()
+    declared = set(re.findall(r"\b(lavie_[a-z0-9_]+)\s*\(", header))
+    declared -= {"lavie_unet_s"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.lavie_abi_version() == 1
+
+
+def test_relpos_buckets_host_function():
+    from lavie_amd import ops
+    for f in (1, 9, 16, 61):
+        assert torch.equal(ops.relpos_buckets(f), O.rel_pos_bucket_table(f, 32, 32))
+    buf = (ctypes.c_int * 4)()
+    assert _lib.load().lavie_relpos_buckets(0, 32, 32, buf) != 0
+    assert b"relpos_buckets" in _lib.load().lavie_last_error()
+
+
+def test_engine_param_inventory_matches_spec():
+    """lavie_unet_create needs no GPU: the engine's own name/numel list equals the Python spec."""
+    from lavie_amd.unet import UNet3DConditionModel
+    lib = _lib.load()
+    net = UNet3DConditionModel(sample_size=8, block_out_channels=(256, 512), cross_attention_dim=128,
+                               down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+                               up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"), init_weights=False)
+    handle = ctypes.c_void_p()
+    cfg = net._config_c()
+    assert lib.lavie_unet_create(ctypes.byref(cfg), ctypes.byref(handle)) == 0
+    try:
+        n = lib.lavie_unet_num_params(handle)
+        got = {}
+        for i in range(n):
+            name, numel = ctypes.c_char_p(), ctypes.c_longlong()
+            assert lib.lavie_unet_param_info(handle, i, ctypes.byref(name), ctypes.byref(numel)) == 0
+            got[name.value.decode()] = numel.value
+        want = {k: math.prod(v) for k, v in spec.param_shapes(net.cfg).items()}
+        assert got == want
+        assert list(got) == [k for k, _ in spec.iter_params(net.cfg)]          # same enumeration order
+        assert lib.lavie_unet_set_param(handle, b"no.such.key", ctypes.c_void_p(16), 1) != 0
+    finally:
+        lib.lavie_unet_destroy(handle)
+
+
+def test_facade_surface_and_errors():
+    from lavie_amd.unet import UNet3DConditionModel
+    net = UNet3DConditionModel(sample_size=8, block_out_channels=(256, 512), cross_attention_dim=128,
+                               down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+                               up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"), init_weights=False)
+    assert net.config.in_channels == 4 and net.config.sample_size == 8
+    assert set(net.state_dict()) == set(spec.param_shapes(net.cfg))
+    with pytest.raises(RuntimeError, match="MI355X only"):       # no silent CPU path
+        net(torch.zeros(2, 4, 4, 8, 8), 10, encoder_hidden_states=torch.zeros(2, 77, 128))
+    with pytest.raises(NotImplementedError):
+        UNet3DConditionModel(use_linear_projection=True, init_weights=False, block_out_channels=(256, 512),
+                             down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+                             up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
+    with pytest.raises(ValueError):
+        UNet3DConditionModel(down_block_types=("Nope", "DownBlock3D"), up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"),
+                             block_out_channels=(256, 512), init_weights=False)
+
+
+def test_product_never_imports_oracle_or_reference():
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|refimport|refbuild|refshim)\b", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lavie_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), f"{f} imports test infrastructure"
+                assert "/root/reference" not in text or f.endswith((".py", ".hip", ".h", ".cpp")), f
+    for f in ("bench.py",):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            assert "refimport" not in open(p).read()

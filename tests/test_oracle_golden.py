@@ -1,0 +1,72 @@
+"""CPU: oracle/ against the committed reference-generated fixtures (runs on the GPU box too,
+where /root/reference does not exist)."""
+import pytest
+import torch
+
+import golden_util as G
+from lavie_amd import spec
+from oracle import unet_fp32 as O
+from oracle.ddpm import cfg_denoise_loop
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+def test_resnet_and_samplers():
+    fx = G.load("resnet.pt")
+    for c in fx["cases"]:
+        sd = G.synth16(c["shapes"], c["seed"], "r.")
+        got = O.resnet_block(sd, "r.", c["x"].float(), c["temb"].float(), O.UNetConfig())
+        assert rel_l2(got, c["y"]) < 1e-5
+    s = fx["sampler"]
+    assert rel_l2(O.upsample(G.synth16(s["up_shapes"], s["up_seed"], "u."), "u.", s["x"].float()), s["up"]) < 1e-5
+    assert rel_l2(O.downsample(G.synth16(s["dn_shapes"], s["dn_seed"], "d."), "d.", s["x"].float()), s["dn"]) < 1e-5
+
+
+def test_temporal_attention():
+    for c in G.load("temporal_attention.pt")["cases"]:
+        sd = G.synth16(c["shapes"], c["seed"], "a.")
+        got = O.temporal_attention(sd, "a.", c["x"].float(), O.UNetConfig())
+        assert rel_l2(got, c["y"]) < 1e-3          # fixture outputs are stored in fp16
+
+
+def test_cross_attention():
+    for c in G.load("cross_attention.pt")["cases"]:
+        sd = G.synth16(c["shapes"], c["seed"], "a.")
+        ctx = None if c["ctx"] is None else c["ctx"].float()
+        got = O.cross_attention(sd, "a.", c["x"].float(), ctx, 8)
+        assert rel_l2(got, c["y"]) < 1e-3
+
+
+def test_transformer3d():
+    fx = G.load("transformer3d.pt")
+    sd = G.synth16(fx["shapes"], fx["seed"], "t.")
+    got = O.transformer3d(sd, "t.", fx["x"].float(), fx["ctx"].float(), O.UNetConfig())
+    assert rel_l2(got, fx["y"]) < 1e-5
+
+
+def test_relpos_buckets():
+    fx = G.load("relpos_buckets.pt")
+    for n, table in fx.items():
+        assert torch.equal(O.rel_pos_bucket_table(int(n), 32, 32), table)
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    return G.synth16(spec.param_shapes(), 0)
+
+
+def test_whole_unet_full_width(full_sd):
+    fx = G.load("unet_full_8x8.pt")
+    for t, ref in fx["y"].items():
+        got = O.unet_forward(full_sd, fx["x"].float(), int(t), fx["ctx"].float())
+        assert rel_l2(got, ref) < 1e-4
+
+
+def test_ddpm_three_steps(full_sd):
+    fx = G.load("ddpm_3step.pt")
+    fn = lambda x, t, c: O.unet_forward(full_sd, x, t, c)
+    got = cfg_denoise_loop(fn, fx["latents"], fx["prompt"].float(), fx["negative"].float(), fx["noises"],
+                           num_steps=50, guidance_scale=7.5, max_steps=3)
+    assert rel_l2(got, fx["y"]) < 1e-4
