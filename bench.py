@@ -64,12 +64,24 @@ def profile_end(lib):
     return [dict(name=CLASS_NAMES[i], launches=int(launches[i]), ms=ms[i], flops=fl[i], bytes=by[i]) for i in range(n)]
 
 
-def cpu_baseline(sd_fp32, sample_frames):
+def host_cores():
+    """CPU threads this process may really use: cgroup quota / affinity, not the host's core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(sd_fp32, sample_frames, threads):
     """Oracle (fp32, all host cores) on a bounded sample: ONE CFG UNet forward at batch 2 with `sample_frames`
     of the 16 frames at the full 40x64 latent.  Every op except the (negligible, 0.1 %) temporal-attention core
     is linear in the frame count, so one video-latent = 50 steps x (16 / sample_frames) x this time."""
     from oracle import unet_fp32 as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 4, sample_frames, LAT_H, LAT_W, generator=g)
     ctx = torch.randn(2, CTX_LEN, CTX_DIM, generator=g)
@@ -91,7 +103,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3, help="timed video-latents per GPU")
     ap.add_argument("--warmup", type=int, default=1, help="untimed video-latents per GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample-frames", type=int, default=2, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample-frames", type=int, default=1, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = cgroup/affinity share)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline instrumentation")
     ap.add_argument("--ddpm-steps", type=int, default=DDPM_STEPS, help=argparse.SUPPRESS)   # debugging only
     args = ap.parse_args()
@@ -227,7 +240,8 @@ def main():
                              gbs=(r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else None)) for r in rows]}
 
     if rank == 0 and world == 1 and args.cpu_sample_frames > 0:
-        result["cpu_baseline"] = cpu_baseline({k: v.float() for k, v in sd32.items()}, args.cpu_sample_frames)
+        result["cpu_baseline"] = cpu_baseline({k: v.float() for k, v in sd32.items()}, args.cpu_sample_frames,
+                                              args.cpu_threads or host_cores())
 
     if rank == 0:
         print(json.dumps(result))
