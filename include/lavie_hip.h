@@ -110,6 +110,8 @@ int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, v
  * algorithmic flops, algorithmic bytes — the per-launch figures are defined in DESIGN.md).
  * ---------------------------------------------------------------------------------------------- */
 #define LAVIE_PROFILE_CLASSES 7
+/* Test/tuning knob for the implicit-GEMM tile choice: 0 automatic, 1 128-row tiles only, 2 256-row tiles. */
+int lavie_debug_force_tile(int mode);
 int lavie_profile_begin(unsigned mask, int max_events);
 int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host);
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "lavie_cfg_ddpm_step": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
                                      c_float, c_float, c_void_p]),
     "lavie_latents_to_model_input": (c_int, [c_float_p, c_void_p, c_ll, c_void_p]),
+    "lavie_debug_force_tile": (c_int, [c_int]),
     "lavie_profile_begin": (c_int, [C.c_uint, c_int]),
     "lavie_profile_end": (c_int, [c_void_p, C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),

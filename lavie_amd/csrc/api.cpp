@@ -142,6 +142,8 @@ int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, v
     return launch_f32_to_f16_dup2(x, H(model_in2), n, S(stream));
 }
 
+int lavie_debug_force_tile(int mode) { igemm_force_tile(mode); return 0; }
+
 int lavie_profile_begin(unsigned mask, int max_events) { return profile_begin(mask, max_events); }
 
 int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host) {

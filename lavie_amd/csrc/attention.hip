@@ -23,12 +23,13 @@
 namespace lavie {
 
 constexpr int ATT_KEYS = 64;   // keys per tile
+constexpr float RESCALE_THR = 8.0f;   // log2 units: running max moves only when a row grows by > 2^8
 
 template <int DHP>
 struct AttTile {
     static constexpr int STRIDE = DHP * 2 + 32;          // bytes per key row in LDS
     static constexpr int TILE_BYTES = ATT_KEYS * STRIDE; // one of K / V
-    static constexpr int LDS_BYTES = 2 * TILE_BYTES;
+    static constexpr int LDS_BYTES = 4 * TILE_BYTES;      // 2 buffers x (K + V)
     static constexpr int KS = DHP / 32;                  // k-steps of the QK^T contraction
     static constexpr int DT = DHP / 16;                  // 16-wide output dim tiles (upper bound)
     static constexpr int MAXPIECE = (ATT_KEYS * (DHP / 8) + 255) / 256;
@@ -56,8 +57,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     // zero the padding columns once (chunks nch .. DHP/8 + 1): staging never writes them
     for (int i = tid; i < ATT_KEYS * (T::STRIDE / 16 - nch); i += 256) {
         const int key = i / (T::STRIDE / 16 - nch), c = nch + i % (T::STRIDE / 16 - nch);
-        *reinterpret_cast<f32x4*>(sK + key * T::STRIDE + c * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(sV + key * T::STRIDE + c * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int buf = 0; buf < 2; ++buf) {
+            *reinterpret_cast<f32x4*>(sK + buf * 2 * T::TILE_BYTES + key * T::STRIDE + c * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(sV + buf * 2 * T::TILE_BYTES + key * T::STRIDE + c * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
 
     // ---- Q fragments (B operand): lane holds Q[q = li][dims 32 ks + 8 g .. +7]
@@ -97,14 +101,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        char* dK = sK + buf * (2 * T::TILE_BYTES);
+        char* dV = sV + buf * (2 * T::TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < T::MAXPIECE; ++i) {
             const int pc = tid + i * 256;
             if (pc < npiece) {
                 const int key = pc / nch, c = pc - key * nch;
-                *reinterpret_cast<half8_t*>(sK + key * T::STRIDE + c * 16) = rk[i];
-                *reinterpret_cast<half8_t*>(sV + key * T::STRIDE + c * 16) = rv[i];
+                *reinterpret_cast<half8_t*>(dK + key * T::STRIDE + c * 16) = rk[i];
+                *reinterpret_cast<half8_t*>(dV + key * T::STRIDE + c * 16) = rv[i];
             }
         }
     };
@@ -114,20 +120,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     for (int dt = 0; dt < T::DT; ++dt)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run[QT], l_run[QT];
+    float m_run[QT], l_run[QT];      // running max (log2 units, scaled) and per-lane partial row sums
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
 
-    const float sl2 = p.scale * 1.4426950408889634f;   // scores in log2 units
+    const float sl2 = p.scale * 1.4426950408889634f;   // softmax scale folded with log2(e): p = exp2(s*sl2 - m)
     const int ntile = cdiv(p.Lk, ATT_KEYS);
     const int ndt = (dh + 15) >> 4;
 
+    // tile 0 -> LDS buffer 0, tile 1 -> registers
     load_tile(0);
-    store_tile();
+    store_tile(0);
+    if (ntile > 1) load_tile(ATT_KEYS);
     __syncthreads();
 
     for (int t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile) load_tile((t + 1) * ATT_KEYS);
+        const char* cK = sK + (t & 1) * (2 * T::TILE_BYTES);
+        const char* cV = sV + (t & 1) * (2 * T::TILE_BYTES);
 
         // ---- S^T[key, q] = K Q^T
         f32x4 s[4][QT];
@@ -139,45 +148,71 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         for (int ks = 0; ks < T::KS; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const half8_t kf = *reinterpret_cast<const half8_t*>(sK + (kt * 16 + li) * T::STRIDE + (ks * 4 + g) * 16);
+                const half8_t kf = *reinterpret_cast<const half8_t*>(cK + (kt * 16 + li) * T::STRIDE + (ks * 4 + g) * 16);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
                     s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
             }
         }
 
-        // ---- online softmax, per query column (lane li of each 16-lane group)
-        const int kleft = p.Lk - t * ATT_KEYS;     // valid keys in this tile (may exceed 64)
+        // ---- keys past Lk exist only in the last tile (wave-uniform branch)
+        const int kleft = p.Lk - t * ATT_KEYS;
+        if (kleft < ATT_KEYS) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + g * 4 + r >= kleft) s[kt][qt][r] = -INFINITY;
+        }
+
+        // ---- online softmax per query column (lane li of each 16-lane group), deferred rescale (T13):
+        // the running max only moves when some row grew by more than 2^RESCALE_THR, so p <= 2^THR (fine in fp16,
+        // sums and O stay in fp32) and the O-wide rescale runs on a handful of tiles instead of every tile.
         half8_t pb[2][QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float mx = -INFINITY;
+            float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 1; kt < 4; ++kt)
+                mx = fmaxf(mx, fmaxf(fmaxf(s[kt][qt][0], s[kt][qt][1]), fmaxf(s[kt][qt][2], s[kt][qt][3])));
+            {   // max over the four 16-lane groups holding the same query: two half-swaps instead of ds_bpermute
+                const unsigned u = __float_as_uint(mx);
+                const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+                const unsigned v = __float_as_uint(mx);
+                const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+            }
+            const float mxs = mx * sl2;
+            if (__builtin_amdgcn_ballot_w64(mxs > m_run[qt] + RESCALE_THR) != 0) {
+                const float m_new = fmaxf(m_run[qt], mxs);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);   // first tile: exp2(-inf) = 0
+                m_run[qt] = m_new;
+                l_run[qt] *= alpha;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[kt][qt][r] * sl2;
-                    if (kt * 16 + g * 4 + r >= kleft) v = -INFINITY;
-                    s[kt][qt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qt], mx);       // finite: every tile holds >= 1 valid key
-            const float alpha = exp2f(m_run[qt] - m_new);
-            m_run[qt] = m_new;
+                for (int dt = 0; dt < T::DT; ++dt) o[dt][qt] *= alpha;
+            }
+            const float nm = -m_run[qt];
             float psum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                float e[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[kt][qt][r] - m_new);
-                    psum += e;
-                    pb[kt >> 1][qt][(kt & 1) * 4 + r] = (half_t)e;
+                    e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], sl2, nm));
+                    psum += e[r];
                 }
-            l_run[qt] = l_run[qt] * alpha + psum;            // per-lane partial; reduced over g at the end
-#pragma unroll
-            for (int dt = 0; dt < T::DT; ++dt) o[dt][qt] *= alpha;
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const half2_t h0 = __builtin_convertvector((f32x2){e[0], e[1]}, half2_t);
+                const half2_t h1 = __builtin_convertvector((f32x2){e[2], e[3]}, half2_t);
+                pb[kt >> 1][qt][(kt & 1) * 4 + 0] = h0[0];
+                pb[kt >> 1][qt][(kt & 1) * 4 + 1] = h0[1];
+                pb[kt >> 1][qt][(kt & 1) * 4 + 2] = h1[0];
+                pb[kt >> 1][qt][(kt & 1) * 4 + 3] = h1[1];
+            }
+            l_run[qt] += psum;                                // per-lane partial; reduced over g at the end
         }
 
         // ---- O^T[dim, q] += V^T P^T  (V^T fragments by hardware-transposed LDS reads)
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int dt = 0; dt < T::DT; ++dt) {
                 if (dt < ndt) {
-                    const char* va = sV + (kt2 * 32 + g * 4 + (li >> 2)) * T::STRIDE + (dt * 16 + (li & 3) * 4) * 2;
+                    const char* va = cV + (kt2 * 32 + g * 4 + (li >> 2)) * T::STRIDE + (dt * 16 + (li & 3) * 4) * 2;
                     const fp16x4_raw lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va));
                     const fp16x4_raw hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va + 16 * T::STRIDE));
                     half8_t vf;
@@ -199,8 +234,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             }
         }
 
-        __syncthreads();                       // everyone is done reading tile t
-        if (t + 1 < ntile) store_tile();
+        // ---- tile t+1 (in registers since the previous iteration) -> the other LDS buffer, which every wave
+        // finished reading before the barrier that ended iteration t-1; then start fetching tile t+2
+        if (t + 1 < ntile) store_tile((t + 1) & 1);
+        if (t + 2 < ntile) load_tile((t + 2) * ATT_KEYS);
         __syncthreads();
     }
 

@@ -46,5 +46,7 @@ enum IgemmEpilogue { EPI_LINEAR = 0, EPI_GEGLU = 1 };
 
 // Picks a tile and launches.  Returns 0 or a negative status with lavie::set_error().
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream);
+// 0 = automatic tile choice, 1 = 128-row tiles only, 2 = 256-row tiles whenever N %% 160 == 0 (tests, A/B timing)
+void igemm_force_tile(int mode);
 
 }  // namespace lavie

@@ -10,11 +10,14 @@ from gpu_util import TOL_OP, f32, h16, q16, rel_l2, rows, unrows
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["auto-tiles", "big-tiles"])
+def ops(request):
+    """Every operator test runs twice: automatic tile choice, and the 256-row / 3-stage GEMM tiles forced."""
     assert torch.cuda.is_available(), "gpu tests need a HIP device"
-    from lavie_amd import ops as o
-    return o
+    from lavie_amd import _lib, ops as o
+    _lib.load().lavie_debug_force_tile(2 if request.param == "big-tiles" else 0)
+    yield o
+    _lib.load().lavie_debug_force_tile(0)
 
 
 def gen(seed):

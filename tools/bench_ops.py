@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the hot operators at the benchmark's real shapes (MI355X).  A/B over GEMM tile modes.
+Usage: python tools/bench_ops.py [linear|conv|attn|all]"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lavie_amd import _lib, ops  # noqa: E402
+
+dev = "cuda"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3      # us
+
+
+def rnd(*shape):
+    return (torch.randn(*shape, device=dev) * 0.5).half()
+
+
+def bench_linear():
+    shapes = []
+    for M, C in ((81920, 320), (20480, 640), (5120, 1280), (1280, 1280)):
+        shapes += [(M, C, C, "out+res"), (M, 3 * C, C, "qkv"), (M, C, 4 * C, "ff2+res"), (M, 8 * C, C, "geglu")]
+    print(f"{'M':>6} {'N':>6} {'K':>5} {'kind':>8} | " + " | ".join(f"mode{m}: us   TF/s   GB/s" for m in (1, 2)))
+    for M, N, K, kind in shapes:
+        a, w = rnd(M, K), rnd(N, K) / math.sqrt(K)
+        bias = torch.randn(N, device=dev)
+        res = rnd(M, N) if "res" in kind else None
+        geglu = kind == "geglu"
+        if geglu:
+            w, bias = ops.pack_geglu(w, bias.half())
+        out = torch.empty(M, N // 2 if geglu else N, dtype=torch.float16, device=dev)
+        row = f"{M:>6} {N:>6} {K:>5} {kind:>8} | "
+        for mode in (1, 2):
+            _lib.load().lavie_debug_force_tile(mode)
+            us = timeit(lambda: ops.linear(a, w, bias=None if kind == "qkv" else bias, residual=res, geglu=geglu, out=out))
+            fl = 2.0 * M * N * K
+            by = 2.0 * (M * K + N * K + out.numel() + (res.numel() if res is not None else 0))
+            row += f"{us:9.1f} {fl / us / 1e6:6.0f} {by / us / 1e3:6.0f} | "
+        print(row)
+    _lib.load().lavie_debug_force_tile(0)
+
+
+def bench_conv():
+    cases = [(32, 40, 64, 320, 0, 320), (32, 40, 64, 640, 0, 320), (32, 40, 64, 320, 320, 320), (32, 40, 64, 640, 320, 320),
+             (32, 20, 32, 640, 0, 640), (32, 20, 32, 640, 640, 640), (32, 20, 32, 1280, 640, 640), (32, 20, 32, 320, 0, 640),
+             (32, 10, 16, 1280, 0, 1280), (32, 10, 16, 1280, 1280, 1280), (32, 10, 16, 640, 0, 1280),
+             (32, 5, 8, 1280, 0, 1280), (32, 5, 8, 1280, 1280, 1280)]
+    print(f"{'NI':>3} {'H':>3} {'W':>3} {'C1':>5} {'C2':>5} {'Cout':>5} | " + " | ".join(f"mode{m}: us   TF/s" for m in (1, 2)))
+    for ni, h, w, c1, c2, cout in cases:
+        x1 = rnd(ni * h * w, c1)
+        x2 = rnd(ni * h * w, c2) if c2 else None
+        wt = rnd(cout, c1 + c2, 3, 3) / math.sqrt(9 * (c1 + c2))
+        wp = ops.pack_conv3x3(wt)
+        bias = torch.randn(cout, device=dev)
+        row = f"{ni:>3} {h:>3} {w:>3} {c1:>5} {c2:>5} {cout:>5} | "
+        for mode in (1, 2):
+            _lib.load().lavie_debug_force_tile(mode)
+            us = timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2))
+            fl = 2.0 * ni * h * w * cout * 9 * (c1 + c2)
+            row += f"{us:9.1f} {fl / us / 1e6:6.0f} | "
+        print(row)
+    _lib.load().lavie_debug_force_tile(0)
+
+
+def bench_attn():
+    print("attention: nb heads L dh | us TF/s")
+    for nb, l, c, lk, div in ((32, 2560, 320, 2560, 1), (32, 640, 640, 640, 1), (32, 160, 1280, 160, 1), (32, 2560, 320, 77, 16)):
+        if lk == l:
+            qkv = rnd(nb * l, 3 * c)
+            fn = lambda: ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], nb=nb, lq=l, lk=l, heads=8)
+        else:
+            q, kv = rnd(nb * l, c), rnd(nb // div * lk, 2 * c)
+            fn = lambda: ops.attention(q, kv[:, :c], kv[:, c:], nb=nb, lq=l, lk=lk, heads=8, kv_batch_div=div)
+        us = timeit(fn)
+        print(f"{nb:>3} 8 {l:>5} x{lk:>5} dh={c // 8:>3} | {us:9.1f} {4.0 * nb * l * lk * c / us / 1e6:6.0f}")
+    print("temporal: B F D C | us GB/s")
+    for d, c in ((2560, 320), (640, 640), (160, 1280)):
+        qkv = rnd(2 * 16 * d, 3 * c)
+        bias = torch.randn(8, 16, 16, device=dev)
+        cos, sin = ops.rotary_tables(16, 32)
+        us = timeit(lambda: ops.temporal_attention(qkv, 2, 16, d, 8, bias, cos, sin))
+        print(f"  2 16 {d:>5} {c:>5} | {us:9.1f} {4.0 * 2 * 16 * d * c * 2 / us / 1e3:6.0f}")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("linear", "all"):
+        bench_linear()
+    if what in ("conv", "all"):
+        bench_conv()
+    if what in ("attn", "all"):
+        bench_attn()
