@@ -60,7 +60,8 @@ int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void
                       void* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const void* zero_page,
                       void* stream);
 
-/* [Cout, Cin, 3, 3] (PyTorch) -> rows of `ld_out` halfs: out[co, col0 + (ky*3+kx)*Cin + ci]. */
+/* [Cout, Cin, 3, 3] (PyTorch) -> rows of `ld_out` halfs in the implicit GEMM's K order (64-channel slab, tap,
+ * channel): out[co, col0 + ((ci/64)*9 + ky*3+kx)*64 + ci%64].  Cin %% 64 == 0. */
 int lavie_pack_conv3x3_f16(const void* w, void* out, int Cout, int Cin, int ld_out, int col0, void* stream);
 /* GEGLU projection [2*inner, K] (+ bias) -> 16-row value/gate interleave expected by lavie_linear_f16(geglu=1). */
 int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float* bias_out, int N, int K, void* stream);
@@ -112,6 +113,10 @@ int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, v
 #define LAVIE_PROFILE_CLASSES 7
 /* Test/tuning knob for the implicit-GEMM tile choice: 0 automatic, 1 128-row tiles only, 2 256-row tiles. */
 int lavie_debug_force_tile(int mode);
+/* Test/tuning knob: force the split-K factor of the implicit GEMM (0 = automatic). */
+int lavie_debug_force_splits(int s);
+/* Diagnostic: op-level conv3x3 + pack use the K order (tap, slab) instead of (slab, tap). */
+int lavie_debug_conv_tap_major(int on);
 int lavie_profile_begin(unsigned mask, int max_events);
 int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host);
 

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblavie_hip.so")
+LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
 ABI_VERSION = 1
 MAX_LEVELS = 8
 
@@ -47,6 +47,8 @@ SIGNATURES = {
                                      c_float, c_float, c_void_p]),
     "lavie_latents_to_model_input": (c_int, [c_float_p, c_void_p, c_ll, c_void_p]),
     "lavie_debug_force_tile": (c_int, [c_int]),
+    "lavie_debug_force_splits": (c_int, [c_int]),
+    "lavie_debug_conv_tap_major": (c_int, [c_int]),
     "lavie_profile_begin": (c_int, [C.c_uint, c_int]),
     "lavie_profile_end": (c_int, [c_void_p, C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
@@ -81,7 +83,12 @@ def load():
             "or make -C lavie_amd/csrc).  lavie_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        try:
+            fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        except AttributeError:
+            if os.environ.get("LAVIE_HIP_LIB"):
+                continue                  # A/B run against an older build: tolerate missing debug symbols
+            raise
         fn.restype = res
         fn.argtypes = args
     if lib.lavie_abi_version() != ABI_VERSION:

@@ -14,6 +14,25 @@ struct lavie_unet_s {
 };
 
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+// Operator-level entry points have no workspace argument: the split-K slab comes from a grow-only scratch
+// buffer owned by the library (allocated outside any stream capture; the engine uses its own workspace).
+static int g_tap_major = 0;   // diagnostic K-order switch for the op-level conv (pack + launch)
+static float* g_slab = nullptr;
+static size_t g_slab_bytes = 0;
+static int op_slab(IgemmParams& p, int epilogue) {
+    p.splits = igemm_plan_splits(p.M, p.N, p.nk, epilogue);
+    p.slab = nullptr;
+    if (p.splits <= 1) return 0;
+    const size_t need = (size_t)p.splits * p.M * p.N * sizeof(float);
+    if (need > g_slab_bytes) {
+        if (g_slab) { LAVIE_HIP(hipDeviceSynchronize()); LAVIE_HIP(hipFree(g_slab)); g_slab = nullptr; g_slab_bytes = 0; }
+        LAVIE_HIP(hipMalloc((void**)&g_slab, need));
+        g_slab_bytes = need;
+    }
+    p.slab = g_slab;
+    return 0;
+}
 static inline const half_t* H(const void* p) { return (const half_t*)p; }
 static inline half_t* H(void* p) { return (half_t*)p; }
 
@@ -33,6 +52,7 @@ int lavie_linear_f16(const void* A, int lda, const void* W, const float* bias, c
     p.A = H(A); p.lda = lda; p.W = H(W); p.ldw = K; p.C = H(C); p.ldc = ldc; p.bias = bias;
     p.bias2 = bias2; p.ldb2 = ldb2; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     p.R = H(R); p.ldr = ldr; p.M = M; p.N = N; p.nk = K / IGEMM_BK;
+    if (int rc = op_slab(p, geglu ? EPI_GEGLU : EPI_LINEAR)) return rc;
     return launch_igemm(p, false, geglu ? EPI_GEGLU : EPI_LINEAR, S(stream));
 }
 
@@ -58,28 +78,28 @@ int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void
     int ns = 0, nk = 0;
     const half_t* src[2] = {H(x1), H(x2)};
     const int srcC[2] = {C1, x2 ? C2 : 0};
-    for (int tap = 0; tap < 9; ++tap)
-        for (int i = 0; i < 2; ++i) {
-            if (!srcC[i]) continue;
-            IgemmSeg& sg = p.seg[ns++];
-            sg.src = src[i]; sg.C = srcC[i]; sg.c0 = 0; sg.nchunks = srcC[i] / IGEMM_BK; sg.dy = tap / 3 - 1; sg.dx = tap % 3 - 1;
-            nk += sg.nchunks;
-        }
+    for (int i = 0; i < 2; ++i) {
+        if (!srcC[i]) continue;
+        IgemmSeg& sg = p.seg[ns++];
+        sg.src = src[i]; sg.C = srcC[i]; sg.c0 = 0; sg.nchunks = srcC[i] / IGEMM_BK; sg.ntaps = 9;
+        nk += 9 * sg.nchunks;
+    }
     const half_t* sc[2] = {H(sc1), H(sc2)};
     const int scC[2] = {sc1 ? SC1 : 0, sc2 ? SC2 : 0};
     for (int i = 0; i < 2; ++i) {
         if (!scC[i]) continue;
         IgemmSeg& sg = p.seg[ns++];
-        sg.src = sc[i]; sg.C = scC[i]; sg.c0 = 0; sg.nchunks = scC[i] / IGEMM_BK; sg.dy = 0; sg.dx = 0;
+        sg.src = sc[i]; sg.C = scC[i]; sg.c0 = 0; sg.nchunks = scC[i] / IGEMM_BK; sg.ntaps = 1;
         nk += sg.nchunks;
     }
-    p.nseg = ns; p.nk = nk; p.ldw = nk * IGEMM_BK;
+    p.nseg = ns; p.nk = nk; p.ldw = nk * IGEMM_BK; p.tap_major = g_tap_major;
+    if (int rc = op_slab(p, EPI_LINEAR)) return rc;
     return launch_igemm(p, true, EPI_LINEAR, S(stream));
 }
 
 int lavie_pack_conv3x3_f16(const void* w, void* out, int Cout, int Cin, int ld_out, int col0, void* stream) {
     LAVIE_CHECK(w && out && ld_out >= col0 + 9 * Cin, "pack_conv3x3: bad arguments");
-    return launch_pack_conv3x3(H(w), H(out), Cout, Cin, ld_out, col0, S(stream));
+    return launch_pack_conv3x3(H(w), H(out), Cout, Cin, ld_out, col0, g_tap_major == 0, S(stream));
 }
 
 int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float* bias_out, int N, int K, void* stream) {
@@ -143,6 +163,8 @@ int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, v
 }
 
 int lavie_debug_force_tile(int mode) { igemm_force_tile(mode); return 0; }
+int lavie_debug_force_splits(int s) { igemm_force_splits(s); return 0; }
+int lavie_debug_conv_tap_major(int on) { g_tap_major = on; return 0; }
 
 int lavie_profile_begin(unsigned mask, int max_events) { return profile_begin(mask, max_events); }
 

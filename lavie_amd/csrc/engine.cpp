@@ -249,12 +249,12 @@ int UNet::pack_resnet(ResnetW* r, hipStream_t s) {
     const half_t* b2 = given(p + ".conv2.bias");
     NEED(w1, p + ".conv1.weight"); NEED(b1, p + ".conv1.bias"); NEED(w2, p + ".conv2.weight"); NEED(b2, p + ".conv2.bias");
     WALLOC(r->w1, half_t, (size_t)r->cout * 9 * r->cin);
-    RUN(launch_pack_conv3x3(w1, r->w1, r->cout, r->cin, 9 * r->cin, 0, s));
+    RUN(launch_pack_conv3x3(w1, r->w1, r->cout, r->cin, 9 * r->cin, 0, true, s));
     WALLOC(r->b1, float, r->cout);
     RUN(launch_f16_to_f32(b1, r->b1, r->cout, s));
     r->ldw2 = 9 * r->cout + (r->shortcut ? r->cin : 0);
     WALLOC(r->w2, half_t, (size_t)r->cout * r->ldw2);
-    RUN(launch_pack_conv3x3(w2, r->w2, r->cout, r->cout, r->ldw2, 0, s));
+    RUN(launch_pack_conv3x3(w2, r->w2, r->cout, r->cout, r->ldw2, 0, true, s));
     WALLOC(r->b2, float, r->cout);
     if (r->shortcut) {
         const half_t* ws = given(p + ".conv_shortcut.weight");
@@ -337,7 +337,7 @@ int UNet::pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStrea
     out->C = C;
     WALLOC(out->w, half_t, (size_t)C * 9 * C);
     WALLOC(out->b, float, C);
-    RUN(launch_pack_conv3x3(w, out->w, C, C, 9 * C, 0, s));
+    RUN(launch_pack_conv3x3(w, out->w, C, C, 9 * C, 0, true, s));
     RUN(launch_f16_to_f32(b, out->b, C, s));
     return 0;
 }
@@ -362,7 +362,7 @@ int UNet::finalize(hipStream_t s) {
         NEED(wo, std::string("conv_out.weight")); NEED(bo, std::string("conv_out.bias"));
         WALLOC(conv_out_w_, half_t, (size_t)c.out_channels * 9 * C0);
         WALLOC(conv_out_b_, float, c.out_channels);
-        RUN(launch_pack_conv3x3(wo, conv_out_w_, c.out_channels, C0, 9 * C0, 0, s));
+        RUN(launch_pack_conv3x3(wo, conv_out_w_, c.out_channels, C0, 9 * C0, 0, false, s));
         RUN(launch_f16_to_f32(bo, conv_out_b_, c.out_channels, s));
         RUN(pack_norm("conv_norm_out", C0, &norm_out_, s));
     }
@@ -434,20 +434,45 @@ struct FwdCtx {
 
 static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const float* bias, int N, int K, const half_t* R,
                   half_t* C, int ldc, int M, int epilogue = EPI_LINEAR) {
-    if (c.dry) return 0;
+    if (c.dry) {   // plan the split-K slab so that prepare() sizes the workspace for it
+        const int s = igemm_plan_splits(M, N, K / IGEMM_BK, epilogue);
+        if (s > 1) {
+            const size_t mark = c.ws->mark();
+            (void)c.ws->alloc((size_t)s * M * N * sizeof(float));
+            c.ws->release(mark);
+        }
+        return 0;
+    }
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.A = A; p.lda = lda; p.W = W; p.ldw = K; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldc;
     p.M = M; p.N = N; p.nk = K / IGEMM_BK;
     LAVIE_CHECK(K % IGEMM_BK == 0, "linear: K=%d must be a multiple of %d", K, IGEMM_BK);
-    return launch_igemm(p, false, epilogue, c.s);
+    p.splits = igemm_plan_splits(M, N, p.nk, epilogue);
+    const size_t mark = c.ws->mark();
+    if (p.splits > 1) {
+        p.slab = (float*)c.ws->alloc((size_t)p.splits * M * N * sizeof(float));
+        LAVIE_CHECK(p.slab != nullptr, "workspace exhausted (split-K slab)");
+    }
+    const int rc = launch_igemm(p, false, epilogue, c.s);
+    c.ws->release(mark);
+    return rc;
 }
 
 // 3x3 conv (pad 1) over `nsrc` channel-concatenated sources, plus optional centre-tap shortcut sources.
 static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsrc, const half_t* const* sc, const int* scC,
                    int nsc, const half_t* W, int ldw, const float* bias, const float* bias2, int ldb2, int rows_per_batch,
                    const half_t* R, half_t* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const half_t* zero) {
-    if (c.dry) return 0;
+    if (c.dry) {
+        const int Ho = ups ? Hi * 2 : (Hi - 1) / stride + 1, Wo = ups ? Wi * 2 : (Wi - 1) / stride + 1;
+        const int s = igemm_plan_splits(NI * Ho * Wo, Cout, ldw / IGEMM_BK, EPI_LINEAR);
+        if (s > 1) {
+            const size_t mark = c.ws->mark();
+            (void)c.ws->alloc((size_t)s * NI * Ho * Wo * Cout * sizeof(float));
+            c.ws->release(mark);
+        }
+        return 0;
+    }
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.W = W; p.ldw = ldw; p.C = y; p.ldc = Cout; p.bias = bias; p.bias2 = bias2; p.ldb2 = ldb2;
@@ -459,25 +484,31 @@ static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsr
     p.N = Cout;
     p.zero = zero;
     int ns = 0, nk = 0;
-    for (int tap = 0; tap < 9; ++tap)
-        for (int i = 0; i < nsrc; ++i) {
-            LAVIE_CHECK(srcC[i] % IGEMM_BK == 0, "conv3x3: channel count %d must be a multiple of %d", srcC[i], IGEMM_BK);
-            IgemmSeg& sg = p.seg[ns++];
-            sg.src = src[i]; sg.C = srcC[i]; sg.c0 = 0; sg.nchunks = srcC[i] / IGEMM_BK;
-            sg.dy = tap / 3 - 1; sg.dx = tap % 3 - 1;
-            nk += sg.nchunks;
-        }
+    LAVIE_CHECK(nsrc + nsc <= IGEMM_MAX_SEG, "conv3x3: too many K segments");
+    for (int i = 0; i < nsrc; ++i) {
+        LAVIE_CHECK(srcC[i] % IGEMM_BK == 0, "conv3x3: channel count %d must be a multiple of %d", srcC[i], IGEMM_BK);
+        IgemmSeg& sg = p.seg[ns++];
+        sg.src = src[i]; sg.C = srcC[i]; sg.c0 = 0; sg.nchunks = srcC[i] / IGEMM_BK; sg.ntaps = 9;
+        nk += 9 * sg.nchunks;
+    }
     for (int i = 0; i < nsc; ++i) {
         LAVIE_CHECK(scC[i] % IGEMM_BK == 0 && stride == 1 && ups == 0, "conv3x3: bad shortcut source");
         IgemmSeg& sg = p.seg[ns++];
-        sg.src = sc[i]; sg.C = scC[i]; sg.c0 = 0; sg.nchunks = scC[i] / IGEMM_BK; sg.dy = 0; sg.dx = 0;
+        sg.src = sc[i]; sg.C = scC[i]; sg.c0 = 0; sg.nchunks = scC[i] / IGEMM_BK; sg.ntaps = 1;
         nk += sg.nchunks;
     }
-    LAVIE_CHECK(ns <= IGEMM_MAX_SEG, "conv3x3: too many K segments (%d)", ns);
     LAVIE_CHECK(nk * IGEMM_BK == ldw, "conv3x3: weight row length %d does not match gathered K %d", ldw, nk * IGEMM_BK);
     p.nseg = ns;
     p.nk = nk;
-    return launch_igemm(p, true, EPI_LINEAR, c.s);
+    p.splits = igemm_plan_splits(p.M, p.N, nk, EPI_LINEAR);
+    const size_t mark = c.ws->mark();
+    if (p.splits > 1) {
+        p.slab = (float*)c.ws->alloc((size_t)p.splits * p.M * p.N * sizeof(float));
+        LAVIE_CHECK(p.slab != nullptr, "workspace exhausted (split-K slab)");
+    }
+    const int rc = launch_igemm(p, true, EPI_LINEAR, c.s);
+    c.ws->release(mark);
+    return rc;
 }
 
 int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, const float* tproj,

@@ -4,18 +4,19 @@
 
 namespace lavie {
 
-constexpr int IGEMM_MAX_SEG = 24;
+constexpr int IGEMM_MAX_SEG = 4;    // two conv sources + two shortcut sources
 constexpr int IGEMM_BK = 64;    // K-tile in halfs: 128-B rows in LDS, one 16x16x32 MFMA pair per tile
 
-// One K-segment of the A operand: `nchunks` K-tiles of 64 channels read from tensor `src`
-// (channels-last rows of `C` halfs) at spatial tap (dy, dx).  A 3x3 conv over a concatenated
-// input [x1 | x2] is 18 segments; a fused 1x1 shortcut appends 1-2 centre-tap segments.
+// One K-segment of the A operand: a source tensor `src` (channels-last rows of `C` halfs) contributing
+// `nchunks` 64-channel slabs, each visited at `ntaps` spatial taps (9 = the 3x3 stencil, 1 = centre only).
+// K order inside a segment: slab-major, tap-minor.  A 3x3 conv over a concatenated input [x1 | x2] is two
+// 9-tap segments; a fused 1x1 shortcut appends one or two 1-tap segments.
 struct IgemmSeg {
     const half_t* src;
     int C;        // row length (channels) of src
     int c0;       // first channel of this segment inside src rows
-    int nchunks;  // number of 64-channel tiles
-    int dy, dx;   // tap offset in the (virtual, i.e. post-upsample) input grid
+    int nchunks;  // number of 64-channel slabs
+    int ntaps;    // 9 or 1
 };
 
 struct IgemmParams {
@@ -34,10 +35,13 @@ struct IgemmParams {
     const half_t* R;      // residual [M, N] (ldr) or nullptr; may alias C
     int ldr;
     int M, N, nk;         // nk = total number of K-tiles
+    int splits;           // split-K factor (1 = none); > 1 needs `slab`
+    float* slab;          // [splits, M, N] fp32 partial sums
     // Gather geometry (GATHER = true): output pixel grid [NI, Ho, Wo], source grid [NI, Hi, Wi],
     // virtual input grid (Hi << ups, Wi << ups) for the folded nearest-x2 upsample.
     int Ho, Wo, Hi, Wi, stride, ups;
     int nseg;
+    int tap_major;        // diagnostic: K order tap > slab instead of slab > tap (needs weights packed to match)
     IgemmSeg seg[IGEMM_MAX_SEG];
     const half_t* zero;   // >= 128 B of zeros: source of out-of-image taps
 };
@@ -46,7 +50,10 @@ enum IgemmEpilogue { EPI_LINEAR = 0, EPI_GEGLU = 1 };
 
 // Picks a tile and launches.  Returns 0 or a negative status with lavie::set_error().
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream);
+// Split-K factor the launcher would like for this problem (1 = none); slab size = splits * M * N floats.
+int igemm_plan_splits(int M, int N, int nk, int epilogue);
 // 0 = automatic tile choice, 1 = 128-row tiles only, 2 = 256-row tiles whenever N %% 160 == 0 (tests, A/B timing)
 void igemm_force_tile(int mode);
+void igemm_force_splits(int s);   // 0 = automatic
 
 }  // namespace lavie

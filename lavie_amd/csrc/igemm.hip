@@ -38,10 +38,13 @@ struct IgemmTile {
     static constexpr int AP = (APIECES + NW - 1) / NW;                 // pieces per wave per stage; when the count
     static constexpr int WP = (WPIECES + NW - 1) / NW;                 // does not divide, the surplus slots re-load
     static constexpr int LOADS = AP + WP;                              // pieces 0.. (same bytes, same place: benign)
+    static constexpr int TAB_BYTES = BM * 9 * 4 + IGEMM_MAX_SEG * 6 * 4;  // GATHER: source-pixel table + segment table
     static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
 };
 
-template <int WM, int WN, int MT, int NT, int NSTAGE, bool GATHER, int EPI>
+// ABL (diagnostic builds only, results are wrong): 1 = no MFMA, 2 = no global loads after the prologue,
+// 3 = loads + barriers only.  Used by tools/bench_ops.py to find which pipeline paces the loop.
+template <int WM, int WN, int MT, int NT, int NSTAGE, bool GATHER, int EPI, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p) {
     using T = IgemmTile<WM, WN, MT, NT, NSTAGE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,27 +69,34 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     const int lr = lane >> 3;                       // row of this lane inside an 8-row piece
     const int kofs = ((lane & 7) ^ lr) * 8;         // source K offset (halfs) after the slot swizzle
 
+    // GATHER: per-block table of source pixels, tab[row * 9 + tap] = pixel index in the source grid or -1
+    // (out of image).  K order is segment > 64-channel chunk > tap: the 9 taps of one channel slab are fetched
+    // back to back, so the shifted re-reads of the same cache lines hit in L1/L2 instead of going to the fabric.
+    int* tab = reinterpret_cast<int*>(smem + T::LDS_BYTES);
     const half_t* aptr[T::AP];
-    int astep[T::AP];
-    int ay[T::AP], ax[T::AP], an[T::AP];
+    int arow[T::AP];
 #pragma unroll
     for (int i = 0; i < T::AP; ++i) {
-        int m = m0 + ((wave + T::NW * i) % T::APIECES) * 8 + lr;
+        arow[i] = ((wave + T::NW * i) % T::APIECES) * 8 + lr;
+        int m = m0 + arow[i];
         m = m < p.M ? m : p.M - 1;
-        if constexpr (GATHER) {
-            const int hw = p.Ho * p.Wo;
-            an[i] = m / hw;
-            const int rem = m - an[i] * hw;
-            const int y = rem / p.Wo;
-            ay[i] = y * p.stride;
-            ax[i] = (rem - y * p.Wo) * p.stride;
-            aptr[i] = p.zero;
-            astep[i] = 0;
-        } else {
-            aptr[i] = p.A + (size_t)m * p.lda + kofs;
-            astep[i] = IGEMM_BK;
-            ay[i] = ax[i] = an[i] = 0;
+        aptr[i] = GATHER ? p.zero : p.A + (size_t)m * p.lda + kofs;
+    }
+    if constexpr (GATHER) {
+        const int hw = p.Ho * p.Wo;
+        const int Hv = p.Hi << p.ups, Wv = p.Wi << p.ups;
+        for (int idx = tid; idx < T::BM * 9; idx += T::THREADS) {
+            const int row = idx / 9, tap = idx - row * 9;
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            const int n = m / hw;
+            const int rem = m - n * hw;
+            const int y = rem / p.Wo, x = rem - y * p.Wo;
+            const int iy = y * p.stride + tap / 3 - 1, ix = x * p.stride + tap % 3 - 1;
+            const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+            tab[idx] = ok ? (n * p.Hi + (iy >> p.ups)) * p.Wi + (ix >> p.ups) : -1;
         }
+        __syncthreads();
     }
     const half_t* wptr[T::WP];
 #pragma unroll
@@ -95,40 +105,107 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         wptr[i] = p.W + (size_t)n * p.ldw + kofs;
     }
 
-    int seg = -1, cseg = 0, seg_chunks = 0;   // gather cursor: current segment / chunk inside it
-    auto enter_segment = [&](int s) {
-        seg = s;
-        cseg = 0;
-        if constexpr (GATHER) {
-            const IgemmSeg sg = p.seg[s];
-            seg_chunks = sg.nchunks;
-            const int Hv = p.Hi << p.ups, Wv = p.Wi << p.ups;
+    // split-K: this workgroup owns K-tiles [t_begin, t_end) of the flattened K loop
+    const int split = blockIdx.y;
+    const int t_begin = (int)((long)p.nk * split / p.splits);
+    const int t_end = (int)((long)p.nk * (split + 1) / p.splits);
+
+    // gather cursor (wave-uniform): segment, channel chunk inside it, tap — positioned at t_begin
+    // constant-index selects keep the segment descriptors in kernarg SGPRs (a runtime index into the by-value
+    // struct would make the compiler spill the whole parameter block to scratch)
+    // Segment descriptors live in LDS (written once with constant indices, read with the runtime segment index):
+    // a runtime index into the by-value kernel-parameter struct would make the compiler copy the whole parameter
+    // block to scratch, and scratch loads are vmcnt-counted VMEM — every one of them inside the K loop would
+    // drain the LDS-DMA pipeline (guide §5, trap (b)).  LDS reads only touch lgkmcnt.
+    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    int* segtab = tab + T::BM * 9;                 // [IGEMM_MAX_SEG][6] : src lo, src hi, C, c0, nchunks, ntaps
+    if constexpr (GATHER) {
+        if (tid == 0) {
 #pragma unroll
-            for (int i = 0; i < T::AP; ++i) {
-                const int iy = ay[i] + sg.dy, ix = ax[i] + sg.dx;
-                const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-                const size_t pix = ((size_t)an[i] * p.Hi + (iy >> p.ups)) * p.Wi + (ix >> p.ups);
-                aptr[i] = ok ? sg.src + pix * sg.C + sg.c0 + kofs : p.zero + kofs;
-                astep[i] = ok ? IGEMM_BK : 0;
+            for (int i = 0; i < IGEMM_MAX_SEG; ++i) {
+                const unsigned long long a = reinterpret_cast<unsigned long long>(p.seg[i].src);
+                segtab[i * 6 + 0] = (int)(unsigned)a;
+                segtab[i * 6 + 1] = (int)(unsigned)(a >> 32);
+                segtab[i * 6 + 2] = p.seg[i].C;
+                segtab[i * 6 + 3] = p.seg[i].c0;
+                segtab[i * 6 + 4] = p.seg[i].nchunks;
+                segtab[i * 6 + 5] = p.seg[i].ntaps;
+            }
+        }
+        __syncthreads();
+    }
+    auto load_seg = [&](int i) -> IgemmSeg {
+        IgemmSeg r;
+        const unsigned lo = (unsigned)sgpr(segtab[i * 6 + 0]), hi = (unsigned)sgpr(segtab[i * 6 + 1]);
+        r.src = reinterpret_cast<const half_t*>(((unsigned long long)hi << 32) | lo);
+        r.C = sgpr(segtab[i * 6 + 2]);
+        r.c0 = sgpr(segtab[i * 6 + 3]);
+        r.nchunks = sgpr(segtab[i * 6 + 4]);
+        r.ntaps = sgpr(segtab[i * 6 + 5]);
+        return r;
+    };
+    const half_t* const zero_page = reinterpret_cast<const half_t*>(
+        ((unsigned long long)(unsigned)sgpr((int)(unsigned)(reinterpret_cast<unsigned long long>(p.zero) >> 32)) << 32) |
+        (unsigned)sgpr((int)(unsigned)reinterpret_cast<unsigned long long>(p.zero)));
+    const int nseg = sgpr(p.nseg), tap_major = sgpr(p.tap_major);
+    int seg = 0, cchunk = 0, tap = 0;
+    IgemmSeg sg = GATHER ? load_seg(0) : IgemmSeg{nullptr, 0, 0, 0, 1};
+    if constexpr (GATHER) {
+        int skip = t_begin;
+        while (skip >= sg.nchunks * sg.ntaps && seg + 1 < nseg) {
+            skip -= sg.nchunks * sg.ntaps;
+            sg = load_seg(++seg);
+        }
+        if (tap_major) {
+            tap = skip / sg.nchunks;
+            cchunk = skip - tap * sg.nchunks;
+        } else {
+            cchunk = skip / sg.ntaps;
+            tap = skip - cchunk * sg.ntaps;
+        }
+    }
+
+    // Source pointers of the NEXT tile to be issued are computed one step ahead (prepare), so that the table
+    // lookup and address arithmetic overlap the MFMAs instead of delaying the LDS-DMA issue after the barrier.
+    const half_t* nptr[T::AP];
+    auto prepare = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < T::AP; ++i) {
+            if constexpr (GATHER) {
+                const int pv = tab[arow[i] * 9 + (sg.ntaps == 9 ? tap : 4)];
+                nptr[i] = pv >= 0 ? sg.src + (size_t)pv * sg.C + (sg.c0 + cchunk * IGEMM_BK + kofs) : zero_page + kofs;
+            } else {
+                nptr[i] = aptr[i] + t * IGEMM_BK;
+            }
+        }
+        if constexpr (GATHER) {
+            if (tap_major) {                        // diagnostic K order: tap outer, channel slab inner
+                if (++cchunk == sg.nchunks) {
+                    cchunk = 0;
+                    if (++tap == sg.ntaps) {
+                        tap = 0;
+                        if (seg + 1 < nseg) sg = load_seg(++seg);
+                    }
+                }
+            } else if (++tap == sg.ntaps) {
+                tap = 0;
+                if (++cchunk == sg.nchunks) {
+                    cchunk = 0;
+                    if (seg + 1 < nseg) sg = load_seg(++seg);
+                }
             }
         }
     };
-    if constexpr (GATHER) enter_segment(0);
-
-    auto stage = [&](int t, int buf) {
+    auto issue = [&](int t, int buf) {
+        if (ABL == 2 && t > t_begin + 1) return;
         char* base = smem + buf * T::STAGE_BYTES;
-        const int kc = GATHER ? cseg : t;
 #pragma unroll
         for (int i = 0; i < T::AP; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(aptr[i] + kc * astep[i]),
-                                             LDS_PTR(base + ((wave + T::NW * i) % T::APIECES) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(nptr[i]), LDS_PTR(base + ((wave + T::NW * i) % T::APIECES) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < T::WP; ++i)
             __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[i] + t * IGEMM_BK),
                                              LDS_PTR(base + T::BM * 128 + ((wave + T::NW * i) % T::WPIECES) * 1024), 16, 0, 0);
-        if constexpr (GATHER) {
-            if (++cseg == seg_chunks && seg + 1 < p.nseg) enter_segment(seg + 1);
-        }
     };
 
     f32x4 acc[NT][MT];
@@ -144,8 +221,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     const int a_frag = (wm * MT * 16 + frow) * 128;
     const int w_frag = T::BM * 128 + (wn * NT * 16 + frow) * 128;
 
-    const int nk = p.nk;
     auto compute = [&](int buf) {
+        if (ABL == 3) return;
         const char* base = smem + buf * T::STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -160,33 +237,46 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) {
+                    if constexpr (ABL == 1) {
+                        asm volatile("" ::"v"(wf[nt]), "v"(af[mt]));      // keep the LDS reads alive
+                    } else {
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+                    }
+                }
         }
     };
     if constexpr (NSTAGE == 2) {
         // one tile in flight: loads of tile t+1 run under the MFMAs of tile t
-        stage(0, 0);
-        for (int t = 0; t < nk; ++t) {
+        prepare(t_begin);
+        issue(t_begin, 0);
+        if (t_begin + 1 < t_end) prepare(t_begin + 1);
+        int buf = 0;
+        for (int t = t_begin; t < t_end; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces of tile t have landed
-            __syncthreads();   // ... and everybody else's; buffer (t+1)&1 is no longer being read
-            if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
-            compute(t & 1);
+            __syncthreads();   // ... and everybody else's; the other buffer is no longer being read
+            if (t + 1 < t_end) issue(t + 1, buf ^ 1);
+            if (t + 2 < t_end) prepare(t + 2);
+            compute(buf);
+            buf ^= 1;
         }
     } else {
         // NSTAGE-1 tiles in flight across the barrier: counted vmcnt + raw s_barrier (a __syncthreads() would
         // drain the LDS-DMA queue, guide §5 "Pipelining across barriers").  Every wave issues exactly
         // T::LOADS LDS-DMA instructions per tile, so "all but the newest (NSTAGE-2)*LOADS" == tile t landed.
         static_assert(NSTAGE == 3, "counted-wait schedule is written for 3 stages");
-        stage(0, 0);
-        if (nk > 1) stage(1, 1);
+        prepare(t_begin);
+        issue(t_begin, 0);
+        if (t_begin + 1 < t_end) { prepare(t_begin + 1); issue(t_begin + 1, 1); }
+        if (t_begin + 2 < t_end) prepare(t_begin + 2);
         int buf = 0;
-        for (int t = 0; t < nk; ++t) {
-            if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::LOADS) : "memory");
+        for (int t = t_begin; t < t_end; ++t) {
+            if (t + 1 < t_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // tile t visible to all; tile t-1's buffer is free
             asm volatile("" ::: "memory");
-            if (t + 2 < nk) stage(t + 2, buf == 0 ? 2 : buf - 1);
+            if (t + 2 < t_end) issue(t + 2, buf == 0 ? 2 : buf - 1);
+            if (t + 3 < t_end) prepare(t + 3);
             compute(buf);
             buf = buf == 2 ? 0 : buf + 1;
         }
@@ -242,6 +332,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
             }
         }
     };
+    if (p.splits > 1) {
+        // partial sums of this K range; bias / residual / rounding happen once in splitk_reduce_kernel
+        float* slab = p.slab + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mrow + mt * 16;
+            if (m < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + ncol + nt * 16) = acc[nt][mt];
+            }
+        }
+        return;
+    }
     using T1 = std::true_type;
     using T0 = std::false_type;
     const int combo = (p.bias ? 1 : 0) | (p.bias2 ? 2 : 0) | (p.R ? 4 : 0);
@@ -257,20 +361,67 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     }
 }
 
+// out[m, n] = sum_s slab[s, m, n] (+ bias[n]) (+ bias2[m / rows_per_batch, n]) (+ R[m, n]); fixed summation order.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int nv = p.N >> 2;
+    if (idx >= (long)p.M * nv) return;
+    const int m = (int)(idx / nv), n = (int)(idx - (long)m * nv) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.slab + (size_t)m * p.N + n);
+    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(p.slab + ((size_t)s * p.M + m) * p.N + n);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.bias2) v += *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)(m / p.rows_per_batch) * p.ldb2 + n);
+    if (p.R) {
+        const half4_t r = *reinterpret_cast<const half4_t*>(p.R + (size_t)m * p.ldr + n);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+    }
+    const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + n) = o;
+}
+
+// Split-K factor for an under-filled grid.  The 128-row tiles run 2 workgroups per CU (512 slots); a grid of
+// `blocks` tiles takes ceil(blocks*S/512) rounds of (nk/S + fixed) K-steps plus a reduce pass over S slabs.
+static int g_force_splits = 0;
+void igemm_force_splits(int s) { g_force_splits = s; }
+
+int igemm_plan_splits(int M, int N, int nk, int epilogue) {
+    if (epilogue != EPI_LINEAR || N % 160 != 0) return 1;
+    if (g_force_splits > 0) return g_force_splits <= nk ? g_force_splits : 1;
+    const long blocks = (long)cdiv(M, 128) * (N / 160);
+    if (blocks >= 1024) return 1;
+    double best = 1e30;
+    int best_s = 1;
+    for (int s = 1; s <= 8; ++s) {
+        if (s > 1 && nk / s < 12) break;
+        const double rounds = (double)((blocks * s + 511) / 512);
+        double cost = rounds * ((double)nk / s + 6.0);
+        if (s > 1) cost += 1.5e-6 * s * (double)M * N;     // slab write + read (~8 s M N bytes at ~4 TB/s) in K-step units of ~1.3 us
+        if (cost < best * 0.93) { best = cost; best_s = s; }
+    }
+    return best_s;
+}
+
 static int g_force_tile = 0;   // 0 auto, 1 small tiles only, 2 big tiles whenever N allows (tests / A-B timing)
 
-template <int WM, int WN, int MT, int NT, int NSTAGE, bool GATHER, int EPI>
+template <int WM, int WN, int MT, int NT, int NSTAGE, bool GATHER, int EPI, int ABL = 0>
 static int launch_tile(const IgemmParams& p, hipStream_t stream) {
     using T = IgemmTile<WM, WN, MT, NT, NSTAGE>;
-    auto kern = igemm_kernel<WM, WN, MT, NT, NSTAGE, GATHER, EPI>;
+    auto kern = igemm_kernel<WM, WN, MT, NT, NSTAGE, GATHER, EPI, ABL>;
+    constexpr int lds = T::LDS_BYTES + (GATHER ? T::TAB_BYTES : 0);
+    static_assert(lds <= 160 * 1024, "tile + pixel table do not fit LDS");
     static bool attr_set = false;   // one per instantiation
     if (!attr_set) {
-        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const int grid = cdiv(p.M, T::BM) * (p.N / T::BN);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), T::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(T::THREADS), lds, stream, p);
     LAVIE_HIP(hipGetLastError());
+    if (p.splits > 1) {
+        const long total = (long)p.M * (p.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+        LAVIE_HIP(hipGetLastError());
+    }
     return 0;
 }
 
@@ -281,10 +432,14 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     ProfileScope prof(gather ? KC_CONV3X3 : KC_LINEAR, stream, 2.0 * p.M * p.N * K,
                       2.0 * ((double)p.M * K / (gather ? 9.0 : 1.0) + (double)p.N * K + (double)p.M * p.N));
     LAVIE_CHECK(p.N % 4 == 0 && p.ldc % 4 == 0, "igemm: N and ldc must be multiples of 4");
+    LAVIE_CHECK(p.splits >= 1 && p.splits <= p.nk && (p.splits == 1 || (p.slab && epilogue == EPI_LINEAR)),
+                "igemm: bad split-K setup (splits=%d)", p.splits);
     // Tile choice.  "big": 256x160, 8 waves, 3 LDS stages (1 workgroup per CU, 2 waves per SIMD) — enough
     // reuse that the L2->LDS stream no longer paces the MFMAs; used when the grid still fills the chip.
     // "small": 128xBN, 4 waves, 2 stages (2 workgroups per CU) for short grids and odd N.
-    const bool big = g_force_tile == 0 ? (p.M >= 256 && (long)cdiv(p.M, 256) * (p.N / 160) >= 256) : g_force_tile == 2;
+    // The 256-row / 8-wave / 3-stage variant measured slower than two independent 128-row workgroups per CU on
+    // every shape of this model (its 8 waves move in lockstep); it is kept for experiments (force mode 2) only.
+    const bool big = (g_force_tile & 0xF) == 2 && p.splits == 1;
     if (epilogue == EPI_GEGLU) {
         LAVIE_CHECK(p.N % 128 == 0, "igemm: GEGLU needs N %% 128 == 0 (N=%d)", p.N);
         LAVIE_CHECK(!p.R && !p.bias2, "igemm: GEGLU epilogue takes no residual / per-batch bias");
@@ -293,9 +448,25 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
     }
     if (p.N % 160 == 0) {
-        if (big)
-            return gather ? launch_tile<4, 2, 4, 5, 3, true, EPI_LINEAR>(p, stream)
-                          : launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR>(p, stream);
+        if (g_force_tile >= 0x10 && gather) {          // diagnostic ablations of the main conv kernel
+            switch (g_force_tile >> 4) {
+                case 1: return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 1>(p, stream);
+                case 2: return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 2>(p, stream);
+                default: return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 3>(p, stream);
+            }
+        }
+        if (g_force_tile >= 0x10 && !gather) {         // diagnostic ablations, plain GEMM: small (mode&0xF==1) or big tile
+            const int abl = g_force_tile >> 4;
+            if ((g_force_tile & 0xF) == 2) {
+                if (abl == 1) return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR, 1>(p, stream);
+                if (abl == 2) return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR, 2>(p, stream);
+                return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR, 3>(p, stream);
+            }
+            if (abl == 1) return launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR, 1>(p, stream);
+            if (abl == 2) return launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR, 2>(p, stream);
+            return launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR, 3>(p, stream);
+        }
+        if (big && !gather) return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR>(p, stream);
         return gather ? launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR>(p, stream)
                       : launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR>(p, stream);
     }

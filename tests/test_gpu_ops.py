@@ -10,14 +10,18 @@ from gpu_util import TOL_OP, f32, h16, q16, rel_l2, rows, unrows
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto-tiles", "big-tiles"])
+@pytest.fixture(scope="module", params=["auto", "big-tiles", "split-k-3"])
 def ops(request):
-    """Every operator test runs twice: automatic tile choice, and the 256-row / 3-stage GEMM tiles forced."""
+    """Every operator test runs three times: automatic choices, the 256-row / 3-stage GEMM tiles forced, and
+    split-K = 3 forced (fp32 slabs + fixed-order reduce) on every implicit GEMM that has >= 3 K-tiles."""
     assert torch.cuda.is_available(), "gpu tests need a HIP device"
     from lavie_amd import _lib, ops as o
-    _lib.load().lavie_debug_force_tile(2 if request.param == "big-tiles" else 0)
+    lib = _lib.load()
+    lib.lavie_debug_force_tile(2 if request.param == "big-tiles" else 0)
+    lib.lavie_debug_force_splits(3 if request.param == "split-k-3" else 0)
     yield o
-    _lib.load().lavie_debug_force_tile(0)
+    lib.lavie_debug_force_tile(0)
+    lib.lavie_debug_force_splits(0)
 
 
 def gen(seed):

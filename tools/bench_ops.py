@@ -104,3 +104,100 @@ if __name__ == "__main__":
         bench_conv()
     if what in ("attn", "all"):
         bench_attn()
+
+
+def bench_ablate():
+    """Diagnostic: which pipeline paces the conv K loop (results are wrong in ablated modes)."""
+    for ni, h, w, c1, c2, cout in ((32, 40, 64, 640, 320, 320), (32, 10, 16, 1280, 0, 1280), (32, 5, 8, 1280, 0, 1280)):
+        x1 = rnd(ni * h * w, c1)
+        x2 = rnd(ni * h * w, c2) if c2 else None
+        wp = ops.pack_conv3x3(rnd(cout, c1 + c2, 3, 3) / math.sqrt(9 * (c1 + c2)))
+        bias = torch.randn(cout, device=dev)
+        row = f"{ni} {h}x{w} {c1}+{c2}->{cout} | "
+        for mode, name in ((1, "full"), (0x11, "noMFMA"), (0x21, "noLoads"), (0x31, "loadsOnly")):
+            _lib.load().lavie_debug_force_tile(mode)
+            us = timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2))
+            row += f"{name} {us:8.1f} us | "
+        print(row)
+    _lib.load().lavie_debug_force_tile(0)
+
+
+def bench_ablate_gemm():
+    for M, N, K in ((20480, 640, 2560), (81920, 320, 1280), (5120, 1280, 5120)):
+        a, w = rnd(M, K), rnd(N, K) / math.sqrt(K)
+        out = torch.empty(M, N, dtype=torch.float16, device=dev)
+        for tile, tname in ((1, "small 128x160 2-stage"), (2, "big 256x160 3-stage")):
+            row = f"{M}x{N}x{K} {tname:24s} | "
+            for abl, name in ((0, "full"), (1, "noMFMA"), (2, "noLoads"), (3, "loadsOnly")):
+                _lib.load().lavie_debug_force_tile(abl * 16 + tile)
+                us = timeit(lambda: ops.linear(a, w, out=out))
+                row += f"{name} {us:8.1f} us | "
+            print(row)
+    _lib.load().lavie_debug_force_tile(0)
+
+
+def bench_splits():
+    """Split-K sweep on the under-filled conv / linear grids."""
+    lib = _lib.load()
+    print("conv: shape | us at S=1,2,3,4,5,6,8")
+    for ni, h, w, c1, c2, cout in ((32, 20, 32, 640, 0, 640), (32, 20, 32, 1280, 640, 640), (32, 10, 16, 1280, 0, 1280),
+                                   (32, 10, 16, 1280, 1280, 1280), (32, 5, 8, 1280, 0, 1280), (32, 5, 8, 1280, 1280, 1280),
+                                   (32, 40, 64, 320, 0, 320)):
+        x1 = rnd(ni * h * w, c1)
+        x2 = rnd(ni * h * w, c2) if c2 else None
+        wp = ops.pack_conv3x3(rnd(cout, c1 + c2, 3, 3) / math.sqrt(9 * (c1 + c2)))
+        bias = torch.randn(cout, device=dev)
+        row = f"{ni} {h}x{w} {c1}+{c2}->{cout} | "
+        for s in (1, 2, 3, 4, 5, 6, 8):
+            lib.lavie_debug_force_splits(s)
+            row += f"{timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2)):7.1f} "
+        lib.lavie_debug_force_splits(0)
+        row += f"| auto {timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2)):7.1f}"
+        print(row)
+    print("linear: M N K | us at S=1,2,3,4,6,8")
+    for M, N, K in ((20480, 640, 640), (20480, 640, 2560), (5120, 1280, 1280), (5120, 1280, 5120), (5120, 3840, 1280),
+                    (1280, 1280, 1280), (1280, 1280, 5120), (1280, 3840, 1280)):
+        a, w, r = rnd(M, K), rnd(N, K) / math.sqrt(K), rnd(M, N)
+        bias = torch.randn(N, device=dev)
+        out = torch.empty(M, N, dtype=torch.float16, device=dev)
+        row = f"{M} {N} {K} | "
+        for s in (1, 2, 3, 4, 6, 8):
+            lib.lavie_debug_force_splits(s)
+            row += f"{timeit(lambda: ops.linear(a, w, bias=bias, residual=r, out=out)):7.1f} "
+        lib.lavie_debug_force_splits(0)
+        row += f"| auto {timeit(lambda: ops.linear(a, w, bias=bias, residual=r, out=out)):7.1f}"
+        print(row)
+
+
+def bench_order():
+    lib = _lib.load()
+    lib.lavie_debug_force_splits(1)
+    print("conv K order: shape | slab>tap us | tap>slab us")
+    for ni, h, w, c1, c2, cout in ((32, 40, 64, 320, 0, 320), (32, 40, 64, 640, 320, 320), (32, 20, 32, 640, 0, 640),
+                                   (32, 20, 32, 1280, 640, 640), (32, 10, 16, 1280, 0, 1280), (32, 5, 8, 1280, 0, 1280)):
+        x1 = rnd(ni * h * w, c1)
+        x2 = rnd(ni * h * w, c2) if c2 else None
+        wt = rnd(cout, c1 + c2, 3, 3) / math.sqrt(9 * (c1 + c2))
+        bias = torch.randn(cout, device=dev)
+        row = f"{ni} {h}x{w} {c1}+{c2}->{cout} | "
+        outs = []
+        for tm in (0, 1):
+            lib.lavie_debug_conv_tap_major(tm)
+            wp = ops.pack_conv3x3(wt)
+            row += f"{timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2)):8.1f} | "
+            outs.append(ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2).float())
+        row += f"max diff {float((outs[0] - outs[1]).abs().max()):.3g}"
+        print(row)
+    lib.lavie_debug_conv_tap_major(0)
+    lib.lavie_debug_force_splits(0)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "order":
+    bench_order()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "splits":
+    bench_splits()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ablate":
+    bench_ablate()
+    bench_ablate_gemm()
