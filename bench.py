@@ -116,11 +116,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists); build with __graft_entry__.build() and run on the GPU box")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    # LAVIE_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): every rank uses device 0 and the collectives go
+    # through gloo, because RCCL refuses two ranks on one device.  Real runs: one GPU per rank, backend nccl = RCCL.
+    share = os.environ.get("LAVIE_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from lavie_amd import _lib, prompt_dp, spec, weights
     from lavie_amd.pipeline_videogen import VideoGenPipeline
@@ -190,7 +197,7 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: base T2V, one prompt per GPU at a time, 16x320x512 "
                                "(latent 4x16x40x64), DDPM 50 steps, CFG 7.5 (UNet batch 2), fp16, random-init 909M-param UNet",
                    "ddpm_steps": args.ddpm_steps, "guidance_scale": GUIDANCE, "latent": [4, FRAMES, LAT_H, LAT_W],
-                   "prompts_per_gpu": args.steps, "parallelism": f"prompt-dp{world}",
+                   "prompts_per_gpu": args.steps, "parallelism": f"prompt-dp{world}" + ("-shared-gpu-rehearsal" if share else ""),
                    "collectives": "1 weight broadcast (setup), 1 latent all_gather (timed)"},
         "outputs_finite": finite,
         "setup_seconds": setup_s,

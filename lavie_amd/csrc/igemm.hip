@@ -19,6 +19,8 @@
 //  * Two LDS stages, one barrier per K-tile: loads of tile t+1 are in flight under the MFMAs of tile t.
 //  * Out-of-image taps read a 128-B zero page instead of branching.
 //  * blockIdx is remapped so that consecutive tiles (which share activation rows) share an XCD L2.
+#include <math.h>
+
 #include <type_traits>
 
 #include "igemm.h"
@@ -385,9 +387,9 @@ static int g_force_splits = 0;
 void igemm_force_splits(int s) { g_force_splits = s; }
 
 int igemm_plan_splits(int M, int N, int nk, int epilogue) {
-    if (epilogue != EPI_LINEAR || N % 160 != 0) return 1;
+    if (epilogue != EPI_LINEAR || N % 64 != 0) return 1;
     if (g_force_splits > 0) return g_force_splits <= nk ? g_force_splits : 1;
-    const long blocks = (long)cdiv(M, 128) * (N / 160);
+    const long blocks = (long)cdiv(M, 128) * cdiv(N, 160);
     if (blocks >= 1024) return 1;
     double best = 1e30;
     int best_s = 1;
@@ -447,7 +449,22 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         if (big) return launch_tile<4, 2, 4, 4, 3, false, EPI_GEGLU>(p, stream);
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
     }
-    if (p.N % 160 == 0) {
+    // Tile width by grid quantisation: the 4-wave tiles run 2 workgroups per CU (512 slots per round); a narrower
+    // tile is a little less efficient per flop (exponent 0.9) but can save a whole round on short grids.
+    int bn = 0;
+    {
+        double best = 1e30;
+        const int cand[3] = {160, 128, 64};
+        for (int i = 0; i < 3; ++i) {
+            if (p.N % cand[i] != 0) continue;
+            const long blocks = (long)cdiv(p.M, 128) * (p.N / cand[i]) * p.splits;
+            const double cost = (double)((blocks + 511) / 512) * pow(cand[i] / 160.0, 0.9);
+            if (cost < best * 0.97) { best = cost; bn = cand[i]; }
+        }
+        if ((g_force_tile & 0xF) != 0 || g_force_tile >= 0x10) bn = p.N % 160 == 0 ? 160 : bn;   // forced modes: widest
+    }
+    LAVIE_CHECK(bn != 0, "igemm: N=%d is not a multiple of 64", p.N);
+    if (bn == 160) {
         if (g_force_tile >= 0x10 && gather) {          // diagnostic ablations of the main conv kernel
             switch (g_force_tile >> 4) {
                 case 1: return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 1>(p, stream);
@@ -470,14 +487,11 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         return gather ? launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR>(p, stream)
                       : launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR>(p, stream);
     }
-    if (p.N % 128 == 0)
+    if (bn == 128)
         return gather ? launch_tile<2, 2, 4, 4, 2, true, EPI_LINEAR>(p, stream)
                       : launch_tile<2, 2, 4, 4, 2, false, EPI_LINEAR>(p, stream);
-    if (p.N % 64 == 0)
-        return gather ? launch_tile<2, 2, 4, 2, 2, true, EPI_LINEAR>(p, stream)
-                      : launch_tile<2, 2, 4, 2, 2, false, EPI_LINEAR>(p, stream);
-    set_error("igemm: N=%d is not a multiple of 64", p.N);
-    return -1;
+    return gather ? launch_tile<2, 2, 4, 2, 2, true, EPI_LINEAR>(p, stream)
+                  : launch_tile<2, 2, 4, 2, 2, false, EPI_LINEAR>(p, stream);
 }
 
 void igemm_force_tile(int mode) { g_force_tile = mode; }
