@@ -117,6 +117,8 @@ int lavie_debug_force_tile(int mode);
 int lavie_debug_force_splits(int s);
 /* Diagnostic: op-level conv3x3 + pack use the K order (tap, slab) instead of (slab, tap). */
 int lavie_debug_conv_tap_major(int on);
+/* Tuning knob: 16-row query tiles per wave in the attention kernel for head dims <= 64 (0 = automatic). */
+int lavie_debug_attention_qt(int qt);
 int lavie_profile_begin(unsigned mask, int max_events);
 int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host);
 

@@ -279,6 +279,9 @@ static int launch_att(const AttnParams& p, hipStream_t stream) {
     return 0;
 }
 
+static int g_force_qt = 0;
+void attention_force_qt(int qt) { g_force_qt = qt; }
+
 int launch_attention(const AttnParams& p, hipStream_t stream) {
     LAVIE_CHECK(p.dh % 8 == 0 && p.dh >= 8 && p.dh <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", p.dh);
     LAVIE_CHECK(p.Lq > 0 && p.Lk > 0 && p.NBq > 0 && p.heads > 0 && p.kv_batch_div > 0, "attention: empty problem");
@@ -287,6 +290,8 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
     ProfileScope prof(KC_ATTENTION, stream, 4.0 * tok_q * p.Lk * width,
                       2.0 * (2.0 * tok_q * width + 2.0 * ((double)p.NBq / p.kv_batch_div) * p.Lk * width));
     const bool big = p.Lq > 64 * 3;     // >= 2 full 128-row blocks: use 32 rows per wave
+    if (g_force_qt == 1 && p.dh <= 64) return launch_att<64, 1>(p, stream);
+    if (g_force_qt == 4 && p.dh <= 64) return launch_att<64, 4>(p, stream);
     if (p.dh <= 64) return big ? launch_att<64, 2>(p, stream) : launch_att<64, 1>(p, stream);
     if (p.dh <= 96) return big ? launch_att<96, 2>(p, stream) : launch_att<96, 1>(p, stream);
     return big ? launch_att<160, 2>(p, stream) : launch_att<160, 1>(p, stream);

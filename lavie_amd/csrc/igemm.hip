@@ -295,11 +295,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             bv[nt] = BIAS ? *reinterpret_cast<const f32x4*>(p.bias + ncol + nt * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_LINEAR) {
+            // per 16-row slice: request every optional operand first, then combine and store (measured: batching
+            // the whole wave tile's loads up front buys nothing and costs ~90 VGPRs)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mrow + mt * 16;
-            const int mc = m < p.M ? m : p.M - 1;                  // clamp: loads stay in bounds, stores are predicated
-            if constexpr (EPI == EPI_LINEAR) {
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mrow + mt * 16;
+                const int mc = m < p.M ? m : p.M - 1;              // clamp: loads stay in bounds, stores are predicated
                 f32x4 b2v[NT];
                 half4_t rv[NT];
 #pragma unroll
@@ -319,10 +321,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
                     const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                     if (m < p.M) *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + ncol + nt * 16) = o;
                 }
-            } else {
-                // GEGLU: W rows are stored as 16-row blocks alternating value / gate (see pack_geglu),
-                // so tile nt (even) holds h and tile nt+1 the matching gate; output column = n / 2.
-                static_assert(EPI != EPI_GEGLU || NT % 2 == 0, "GEGLU needs value/gate tile pairs");
+            }
+        } else {
+            // GEGLU: W rows are stored as 16-row blocks alternating value / gate (see pack_geglu),
+            // so tile nt (even) holds h and tile nt+1 the matching gate; output column = n / 2.
+            static_assert(EPI != EPI_GEGLU || NT % 2 == 0, "GEGLU needs value/gate tile pairs");
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mrow + mt * 16;
 #pragma unroll
                 for (int nt = 0; nt < NT; nt += 2) {
                     const f32x4 h = acc[nt][mt] + bv[nt], g = acc[nt + 1][mt] + bv[nt + 1];

@@ -27,6 +27,7 @@ struct AttnParams {
     float scale;
 };
 int launch_attention(const AttnParams& p, hipStream_t stream);
+void attention_force_qt(int qt);   // tuning knob: query tiles per wave for head dims <= 64 (0 = automatic)
 
 // ---- temporal_attention.hip
 struct TemporalParams {

@@ -76,7 +76,17 @@ def bench_conv():
     _lib.load().lavie_debug_force_tile(0)
 
 
+def bench_attn_qt():
+    qkv = rnd(32 * 2560, 960)
+    for qt in (1, 2, 4):
+        _lib.load().lavie_debug_attention_qt(qt)
+        us = timeit(lambda: ops.attention(qkv[:, :320], qkv[:, 320:640], qkv[:, 640:], nb=32, lq=2560, lk=2560, heads=8))
+        print(f"L0 self-attention QT={qt}: {us:8.1f} us {4.0 * 32 * 2560 * 2560 * 320 / us / 1e6:6.0f} TF/s")
+    _lib.load().lavie_debug_attention_qt(0)
+
+
 def bench_attn():
+    bench_attn_qt()
     print("attention: nb heads L dh | us TF/s")
     for nb, l, c, lk, div in ((32, 2560, 320, 2560, 1), (32, 640, 640, 640, 1), (32, 160, 1280, 160, 1), (32, 2560, 320, 77, 16)):
         if lk == l:
