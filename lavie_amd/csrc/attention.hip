@@ -35,7 +35,8 @@ struct AttTile {
     static constexpr int MAXPIECE = (ATT_KEYS * (DHP / 8) + 255) / 256;
 };
 
-template <int DHP, int QT>
+// ABL (diagnostic, wrong results): 1 = no softmax VALU (P := S), 2 = no MFMA, 3 = staging + barriers only
+template <int DHP, int QT, int ABL = 0>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     using T = AttTile<DHP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,19 +82,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 
     const half_t* kbase = p.k + (size_t)kvb * p.Lk * p.ldk + head * dh;
     const half_t* vbase = p.v + (size_t)kvb * p.Lk * p.ldv + head * dh;
+    // staging plan of this thread, fixed for the whole loop (no per-tile index arithmetic): piece i covers
+    // 16 bytes of key `pkey[i]` of the tile; a negative key marks an unused slot
     const int npiece = ATT_KEYS * nch;
     half8_t rk[T::MAXPIECE], rv[T::MAXPIECE];
+    int pkey[T::MAXPIECE], lofs[T::MAXPIECE];
+    size_t kofs_g[T::MAXPIECE], vofs_g[T::MAXPIECE];
+#pragma unroll
+    for (int i = 0; i < T::MAXPIECE; ++i) {
+        const int pc = tid + i * 256;
+        const int key = pc / nch, c = pc - key * nch;
+        pkey[i] = pc < npiece ? key : -(1 << 30);
+        lofs[i] = key * T::STRIDE + c * 16;
+        kofs_g[i] = (size_t)key * p.ldk + c * 8;
+        vofs_g[i] = (size_t)key * p.ldv + c * 8;
+    }
 
     auto load_tile = [&](int key0) {
+        const half_t* kt0 = kbase + (size_t)key0 * p.ldk;
+        const half_t* vt0 = vbase + (size_t)key0 * p.ldv;
 #pragma unroll
         for (int i = 0; i < T::MAXPIECE; ++i) {
-            const int pc = tid + i * 256;
-            if (pc < npiece) {
-                const int key = pc / nch, c = pc - key * nch;
-                const int kg = key0 + key;
-                if (kg < p.Lk) {
-                    rk[i] = *reinterpret_cast<const half8_t*>(kbase + (size_t)kg * p.ldk + c * 8);
-                    rv[i] = *reinterpret_cast<const half8_t*>(vbase + (size_t)kg * p.ldv + c * 8);
+            if (pkey[i] >= 0) {
+                if (key0 + pkey[i] < p.Lk) {
+                    rk[i] = *reinterpret_cast<const half8_t*>(kt0 + kofs_g[i]);
+                    rv[i] = *reinterpret_cast<const half8_t*>(vt0 + vofs_g[i]);
                 } else {
                     rk[i] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
                     rv[i] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
@@ -106,11 +119,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         char* dV = sV + buf * (2 * T::TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < T::MAXPIECE; ++i) {
-            const int pc = tid + i * 256;
-            if (pc < npiece) {
-                const int key = pc / nch, c = pc - key * nch;
-                *reinterpret_cast<half8_t*>(dK + key * T::STRIDE + c * 16) = rk[i];
-                *reinterpret_cast<half8_t*>(dV + key * T::STRIDE + c * 16) = rv[i];
+            if (pkey[i] >= 0) {
+                *reinterpret_cast<half8_t*>(dK + lofs[i]) = rk[i];
+                *reinterpret_cast<half8_t*>(dV + lofs[i]) = rv[i];
             }
         }
     };
@@ -150,8 +161,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             for (int kt = 0; kt < 4; ++kt) {
                 const half8_t kf = *reinterpret_cast<const half8_t*>(cK + (kt * 16 + li) * T::STRIDE + (ks * 4 + g) * 16);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
+                for (int qt = 0; qt < QT; ++qt) {
+                    if constexpr (ABL >= 2) asm volatile("" ::"v"(kf));
+                    else s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
+                }
             }
         }
 
@@ -167,10 +180,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                         if (kt * 16 + g * 4 + r >= kleft) s[kt][qt][r] = -INFINITY;
         }
 
+        half8_t pb[2][QT];
+        if constexpr (ABL == 1 || ABL == 3) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pb[kt >> 1][qt][(kt & 1) * 4 + r] = (half_t)s[kt][qt][r];
+        } else {
         // ---- online softmax per query column (lane li of each 16-lane group), deferred rescale (T13):
         // the running max only moves when some row grew by more than 2^RESCALE_THR, so p <= 2^THR (fine in fp16,
         // sums and O stay in fp32) and the O-wide rescale runs on a handful of tiles instead of every tile.
-        half8_t pb[2][QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
@@ -215,6 +236,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             l_run[qt] += psum;                                // per-lane partial; reduced over g at the end
         }
 
+        }
         // ---- O^T[dim, q] += V^T P^T  (V^T fragments by hardware-transposed LDS reads)
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2) {
@@ -228,8 +250,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
                     __builtin_memcpy(&vf, &lo, 8);
                     __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[kt2][qt], o[dt][qt], 0, 0, 0);
+                    for (int qt = 0; qt < QT; ++qt) {
+                        if constexpr (ABL >= 2) asm volatile("" ::"v"(vf), "v"(pb[kt2][qt]));
+                        else o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[kt2][qt], o[dt][qt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -264,10 +288,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     }
 }
 
-template <int DHP, int QT>
+template <int DHP, int QT, int ABL = 0>
 static int launch_att(const AttnParams& p, hipStream_t stream) {
     using T = AttTile<DHP>;
-    auto kern = attention_kernel<DHP, QT>;
+    auto kern = attention_kernel<DHP, QT, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
@@ -290,6 +314,9 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
     ProfileScope prof(KC_ATTENTION, stream, 4.0 * tok_q * p.Lk * width,
                       2.0 * (2.0 * tok_q * width + 2.0 * ((double)p.NBq / p.kv_batch_div) * p.Lk * width));
     const bool big = p.Lq > 64 * 3;     // >= 2 full 128-row blocks: use 32 rows per wave
+    if (g_force_qt == 0x12 && p.dh <= 64) return launch_att<64, 2, 1>(p, stream);
+    if (g_force_qt == 0x22 && p.dh <= 64) return launch_att<64, 2, 2>(p, stream);
+    if (g_force_qt == 0x32 && p.dh <= 64) return launch_att<64, 2, 3>(p, stream);
     if (g_force_qt == 1 && p.dh <= 64) return launch_att<64, 1>(p, stream);
     if (g_force_qt == 4 && p.dh <= 64) return launch_att<64, 4>(p, stream);
     if (p.dh <= 64) return big ? launch_att<64, 2>(p, stream) : launch_att<64, 1>(p, stream);
