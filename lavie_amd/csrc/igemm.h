@@ -50,6 +50,8 @@ enum IgemmEpilogue { EPI_LINEAR = 0, EPI_GEGLU = 1 };
 
 // Picks a tile and launches.  Returns 0 or a negative status with lavie::set_error().
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream);
+// 256x160 phase-alternating kernel (igemm_big.hip); EPI_LINEAR only, the caller runs the split-K reduce.
+int launch_igemm_big(const IgemmParams& p, bool gather, hipStream_t stream);
 // Split-K factor the launcher would like for this problem (1 = none); slab size = splits * M * N floats.
 int igemm_plan_splits(int M, int N, int nk, int epilogue);
 // 0 = automatic tile choice, 1 = 128-row tiles only, 2 = 256-row tiles whenever N %% 160 == 0 (tests, A/B timing)

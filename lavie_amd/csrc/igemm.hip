@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "igemm.h"
+#include "igemm_epilogue.h"
 #include "profile.h"
 
 namespace lavie {
@@ -284,89 +285,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         }
     }
 
-    // ---- epilogue: lane holds channels n..n+3 of token m for every (nt, mt) ----
-    // Which optional operands exist is decided ONCE (wave-uniform) and the body is instantiated per
-    // combination: per-element "if (ptr) load" makes hipcc wait vmcnt(0) after every load (guide §5, trap (c)).
-    const int mrow = m0 + wm * MT * 16 + (lane & 15);
-    const int ncol = n0 + wn * NT * 16 + (lane >> 4) * 4;
-    auto epilogue = [&](auto has_bias, auto has_b2, auto has_res) {
-        constexpr bool BIAS = decltype(has_bias)::value, B2 = decltype(has_b2)::value, RES = decltype(has_res)::value;
-        f32x4 bv[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            bv[nt] = BIAS ? *reinterpret_cast<const f32x4*>(p.bias + ncol + nt * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI == EPI_LINEAR) {
-            // per 16-row slice: request every optional operand first, then combine and store (measured: batching
-            // the whole wave tile's loads up front buys nothing and costs ~90 VGPRs)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = mrow + mt * 16;
-                const int mc = m < p.M ? m : p.M - 1;              // clamp: loads stay in bounds, stores are predicated
-                f32x4 b2v[NT];
-                half4_t rv[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if constexpr (B2)
-                        b2v[nt] = *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)(mc / p.rows_per_batch) * p.ldb2 + ncol + nt * 16);
-                    if constexpr (RES)
-                        rv[nt] = *reinterpret_cast<const half4_t*>(p.R + (size_t)mc * p.ldr + ncol + nt * 16);
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    f32x4 v = acc[nt][mt] + bv[nt];
-                    if constexpr (B2) v += b2v[nt];
-                    if constexpr (RES) {
-                        v[0] += (float)rv[nt][0]; v[1] += (float)rv[nt][1]; v[2] += (float)rv[nt][2]; v[3] += (float)rv[nt][3];
-                    }
-                    const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    if (m < p.M) *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + ncol + nt * 16) = o;
-                }
-            }
-        } else {
-            // GEGLU: W rows are stored as 16-row blocks alternating value / gate (see pack_geglu),
-            // so tile nt (even) holds h and tile nt+1 the matching gate; output column = n / 2.
-            static_assert(EPI != EPI_GEGLU || NT % 2 == 0, "GEGLU needs value/gate tile pairs");
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = mrow + mt * 16;
-#pragma unroll
-                for (int nt = 0; nt < NT; nt += 2) {
-                    const f32x4 h = acc[nt][mt] + bv[nt], g = acc[nt + 1][mt] + bv[nt + 1];
-                    const int no = (n0 + wn * NT * 16 + nt * 16) / 2 + (lane >> 4) * 4;
-                    const half4_t o = {(half_t)(h[0] * gelu_erf_f(g[0])), (half_t)(h[1] * gelu_erf_f(g[1])),
-                                       (half_t)(h[2] * gelu_erf_f(g[2])), (half_t)(h[3] * gelu_erf_f(g[3]))};
-                    if (m < p.M) *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + no) = o;
-                }
-            }
-        }
-    };
-    if (p.splits > 1) {
-        // partial sums of this K range; bias / residual / rounding happen once in splitk_reduce_kernel
-        float* slab = p.slab + (size_t)split * p.M * p.N;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mrow + mt * 16;
-            if (m < p.M) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + ncol + nt * 16) = acc[nt][mt];
-            }
-        }
-        return;
-    }
-    using T1 = std::true_type;
-    using T0 = std::false_type;
-    const int combo = (p.bias ? 1 : 0) | (p.bias2 ? 2 : 0) | (p.R ? 4 : 0);
-    switch (combo) {
-        case 0: epilogue(T0{}, T0{}, T0{}); break;
-        case 1: epilogue(T1{}, T0{}, T0{}); break;
-        case 2: epilogue(T0{}, T1{}, T0{}); break;
-        case 3: epilogue(T1{}, T1{}, T0{}); break;
-        case 4: epilogue(T0{}, T0{}, T1{}); break;
-        case 5: epilogue(T1{}, T0{}, T1{}); break;
-        case 6: epilogue(T0{}, T1{}, T1{}); break;
-        default: epilogue(T1{}, T1{}, T1{}); break;
-    }
+    igemm_epilogue<MT, NT, EPI>(p, acc, m0 + wm * MT * 16 + (lane & 15), n0 + wn * NT * 16 + (lane >> 4) * 4,
+                                n0 + wn * NT * 16, lane, split);
 }
 
 // out[m, n] = sum_s slab[s, m, n] (+ bias[n]) (+ bias2[m / rows_per_batch, n]) (+ R[m, n]); fixed summation order.
@@ -389,6 +309,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
 
 // Split-K factor for an under-filled grid.  The 128-row tiles run 2 workgroups per CU (512 slots); a grid of
 // `blocks` tiles takes ceil(blocks*S/512) rounds of (nk/S + fixed) K-steps plus a reduce pass over S slabs.
+static bool g_big_auto = false;    // flipped on once the big kernel wins on the shapes above
 static int g_force_splits = 0;
 void igemm_force_splits(int s) { g_force_splits = s; }
 
@@ -407,6 +328,15 @@ int igemm_plan_splits(int M, int N, int nk, int epilogue) {
         if (cost < best * 0.93) { best = cost; best_s = s; }
     }
     return best_s;
+}
+
+// Shapes for which the 256x160 phase-alternating kernel (igemm_big.hip) is used.  Filled from measurements
+// (tools/bench_ops.py): it needs a grid of at least one workgroup per CU and enough K-tiles to amortise its
+// longer prologue.
+static bool igemm_prefers_big(int M, int N, int nk, int splits) {
+    if (N % 160 != 0 || splits != 1) return false;
+    const long blocks = (long)cdiv(M, 256) * (N / 160);
+    return g_big_auto && blocks >= 256 && nk >= 8;
 }
 
 static int g_force_tile = 0;   // 0 auto, 1 small tiles only, 2 big tiles whenever N allows (tests / A-B timing)
@@ -433,6 +363,8 @@ static int launch_tile(const IgemmParams& p, hipStream_t stream) {
     return 0;
 }
 
+#define RUN_BIG(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
+
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream) {
     LAVIE_CHECK(p.M > 0 && p.N > 0 && p.nk > 0, "igemm: empty problem M=%d N=%d nk=%d", p.M, p.N, p.nk);
     const double K = (double)p.nk * IGEMM_BK;
@@ -447,7 +379,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     // "small": 128xBN, 4 waves, 2 stages (2 workgroups per CU) for short grids and odd N.
     // The 256-row / 8-wave / 3-stage variant measured slower than two independent 128-row workgroups per CU on
     // every shape of this model (its 8 waves move in lockstep); it is kept for experiments (force mode 2) only.
-    const bool big = (g_force_tile & 0xF) == 2 && p.splits == 1;
+    const bool big = (g_force_tile & 0xF) == 2 || ((g_force_tile & 0xF) == 0 && igemm_prefers_big(p.M, p.N, p.nk, p.splits));
     if (epilogue == EPI_GEGLU) {
         LAVIE_CHECK(p.N % 128 == 0, "igemm: GEGLU needs N %% 128 == 0 (N=%d)", p.N);
         LAVIE_CHECK(!p.R && !p.bias2, "igemm: GEGLU epilogue takes no residual / per-batch bias");
@@ -478,7 +410,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
                 default: return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 3>(p, stream);
             }
         }
-        if (g_force_tile >= 0x10 && !gather) {         // diagnostic ablations, plain GEMM: small (mode&0xF==1) or big tile
+        if (g_force_tile >= 0x10 && !gather && (g_force_tile & 0xF) != 2) {   // diagnostic ablations of the small plain tile
             const int abl = g_force_tile >> 4;
             if ((g_force_tile & 0xF) == 2) {
                 if (abl == 1) return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR, 1>(p, stream);
@@ -489,7 +421,15 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
             if (abl == 2) return launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR, 2>(p, stream);
             return launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR, 3>(p, stream);
         }
-        if (big && !gather) return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR>(p, stream);
+        if (big) {
+            RUN_BIG(launch_igemm_big(p, gather, stream));
+            if (p.splits > 1) {
+                const long total = (long)p.M * (p.N / 4);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+                LAVIE_HIP(hipGetLastError());
+            }
+            return 0;
+        }
         return gather ? launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR>(p, stream)
                       : launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR>(p, stream);
     }
@@ -500,6 +440,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
                   : launch_tile<2, 2, 4, 2, 2, false, EPI_LINEAR>(p, stream);
 }
 
-void igemm_force_tile(int mode) { g_force_tile = mode; }
+void igemm_big_ablate(int a);
+void igemm_force_tile(int mode) { g_force_tile = mode; igemm_big_ablate((mode & 0xF) == 2 ? mode >> 4 : 0); }
 
 }  // namespace lavie

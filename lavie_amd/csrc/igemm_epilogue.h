@@ -1,0 +1,97 @@
+// Shared epilogue of the implicit-GEMM kernels (igemm.hip, igemm_big.hip).
+#pragma once
+#include <type_traits>
+
+#include "igemm.h"
+
+namespace lavie {
+
+// Lane layout on entry (v_mfma_f32_16x16x32_f16 with the weight tile as the A operand): acc[nt][mt][r] is output
+// channel ncol + nt*16 + r of token mrow + mt*16.  `nwave0` = first channel of this wave's tile (GEGLU column maths).
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int mrow, int ncol, int nwave0,
+                                               int lane, int split) {
+    // ---- epilogue: lane holds channels n..n+3 of token m for every (nt, mt) ----
+    // Which optional operands exist is decided ONCE (wave-uniform) and the body is instantiated per
+    // combination: per-element "if (ptr) load" makes hipcc wait vmcnt(0) after every load (guide §5, trap (c)).
+    auto epilogue = [&](auto has_bias, auto has_b2, auto has_res) {
+        constexpr bool BIAS = decltype(has_bias)::value, B2 = decltype(has_b2)::value, RES = decltype(has_res)::value;
+        f32x4 bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            bv[nt] = BIAS ? *reinterpret_cast<const f32x4*>(p.bias + ncol + nt * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == EPI_LINEAR) {
+            // per 16-row slice: request every optional operand first, then combine and store (measured: batching
+            // the whole wave tile's loads up front buys nothing and costs ~90 VGPRs)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mrow + mt * 16;
+                const int mc = m < p.M ? m : p.M - 1;              // clamp: loads stay in bounds, stores are predicated
+                f32x4 b2v[NT];
+                half4_t rv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if constexpr (B2)
+                        b2v[nt] = *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)(mc / p.rows_per_batch) * p.ldb2 + ncol + nt * 16);
+                    if constexpr (RES)
+                        rv[nt] = *reinterpret_cast<const half4_t*>(p.R + (size_t)mc * p.ldr + ncol + nt * 16);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x4 v = acc[nt][mt] + bv[nt];
+                    if constexpr (B2) v += b2v[nt];
+                    if constexpr (RES) {
+                        v[0] += (float)rv[nt][0]; v[1] += (float)rv[nt][1]; v[2] += (float)rv[nt][2]; v[3] += (float)rv[nt][3];
+                    }
+                    const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    if (m < p.M) *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + ncol + nt * 16) = o;
+                }
+            }
+        } else {
+            // GEGLU: W rows are stored as 16-row blocks alternating value / gate (see pack_geglu),
+            // so tile nt (even) holds h and tile nt+1 the matching gate; output column = n / 2.
+            static_assert(EPI != EPI_GEGLU || NT % 2 == 0, "GEGLU needs value/gate tile pairs");
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mrow + mt * 16;
+#pragma unroll
+                for (int nt = 0; nt < NT; nt += 2) {
+                    const f32x4 h = acc[nt][mt] + bv[nt], g = acc[nt + 1][mt] + bv[nt + 1];
+                    const int no = (nwave0 + nt * 16) / 2 + (lane >> 4) * 4;
+                    const half4_t o = {(half_t)(h[0] * gelu_erf_f(g[0])), (half_t)(h[1] * gelu_erf_f(g[1])),
+                                       (half_t)(h[2] * gelu_erf_f(g[2])), (half_t)(h[3] * gelu_erf_f(g[3]))};
+                    if (m < p.M) *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + no) = o;
+                }
+            }
+        }
+    };
+    if (p.splits > 1) {
+        // partial sums of this K range; bias / residual / rounding happen once in splitk_reduce_kernel
+        float* slab = p.slab + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mrow + mt * 16;
+            if (m < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + ncol + nt * 16) = acc[nt][mt];
+            }
+        }
+        return;
+    }
+    using T1 = std::true_type;
+    using T0 = std::false_type;
+    const int combo = (p.bias ? 1 : 0) | (p.bias2 ? 2 : 0) | (p.R ? 4 : 0);
+    switch (combo) {
+        case 0: epilogue(T0{}, T0{}, T0{}); break;
+        case 1: epilogue(T1{}, T0{}, T0{}); break;
+        case 2: epilogue(T0{}, T1{}, T0{}); break;
+        case 3: epilogue(T1{}, T1{}, T0{}); break;
+        case 4: epilogue(T0{}, T0{}, T1{}); break;
+        case 5: epilogue(T1{}, T0{}, T1{}); break;
+        case 6: epilogue(T0{}, T1{}, T1{}); break;
+        default: epilogue(T1{}, T1{}, T1{}); break;
+    }
+}
+
+}  // namespace lavie

@@ -34,7 +34,7 @@ def bench_linear():
     shapes = []
     for M, C in ((81920, 320), (20480, 640), (5120, 1280), (1280, 1280)):
         shapes += [(M, C, C, "out+res"), (M, 3 * C, C, "qkv"), (M, C, 4 * C, "ff2+res"), (M, 8 * C, C, "geglu")]
-    print(f"{'M':>6} {'N':>6} {'K':>5} {'kind':>8} | " + " | ".join(f"mode{m}: us   TF/s   GB/s" for m in (0, 1)))
+    print(f"{'M':>6} {'N':>6} {'K':>5} {'kind':>8} | " + " | ".join(f"mode{m}: us   TF/s   GB/s" for m in (0, 2)))
     for M, N, K, kind in shapes:
         a, w = rnd(M, K), rnd(N, K) / math.sqrt(K)
         bias = torch.randn(N, device=dev)
@@ -44,7 +44,7 @@ def bench_linear():
             w, bias = ops.pack_geglu(w, bias.half())
         out = torch.empty(M, N // 2 if geglu else N, dtype=torch.float16, device=dev)
         row = f"{M:>6} {N:>6} {K:>5} {kind:>8} | "
-        for mode in (0, 1):
+        for mode in (0, 2):
             _lib.load().lavie_debug_force_tile(mode)
             us = timeit(lambda: ops.linear(a, w, bias=None if kind == "qkv" else bias, residual=res, geglu=geglu, out=out))
             fl = 2.0 * M * N * K
@@ -59,7 +59,7 @@ def bench_conv():
              (32, 20, 32, 640, 0, 640), (32, 20, 32, 640, 640, 640), (32, 20, 32, 1280, 640, 640), (32, 20, 32, 320, 0, 640),
              (32, 10, 16, 1280, 0, 1280), (32, 10, 16, 1280, 1280, 1280), (32, 10, 16, 640, 0, 1280),
              (32, 5, 8, 1280, 0, 1280), (32, 5, 8, 1280, 1280, 1280)]
-    print(f"{'NI':>3} {'H':>3} {'W':>3} {'C1':>5} {'C2':>5} {'Cout':>5} | " + " | ".join(f"mode{m}: us   TF/s" for m in (0, 1)))
+    print(f"{'NI':>3} {'H':>3} {'W':>3} {'C1':>5} {'C2':>5} {'Cout':>5} | " + " | ".join(f"mode{m}: us   TF/s" for m in (0, 2)))
     for ni, h, w, c1, c2, cout in cases:
         x1 = rnd(ni * h * w, c1)
         x2 = rnd(ni * h * w, c2) if c2 else None
@@ -67,7 +67,7 @@ def bench_conv():
         wp = ops.pack_conv3x3(wt)
         bias = torch.randn(cout, device=dev)
         row = f"{ni:>3} {h:>3} {w:>3} {c1:>5} {c2:>5} {cout:>5} | "
-        for mode in (0, 1):
+        for mode in (0, 2):
             _lib.load().lavie_debug_force_tile(mode)
             us = timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2))
             fl = 2.0 * ni * h * w * cout * 9 * (c1 + c2)
