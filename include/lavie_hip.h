@@ -119,6 +119,8 @@ int lavie_debug_force_splits(int s);
 int lavie_debug_conv_tap_major(int on);
 /* Tuning knob: 16-row query tiles per wave in the attention kernel for head dims <= 64 (0 = automatic). */
 int lavie_debug_attention_qt(int qt);
+/* Tuning knob: LDS bytes one temporal-attention workgroup may stage (smaller = more workgroups per CU). */
+int lavie_debug_temporal_budget(int bytes);
 int lavie_profile_begin(unsigned mask, int max_events);
 int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host);
 

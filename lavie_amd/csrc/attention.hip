@@ -37,7 +37,7 @@ struct AttTile {
 
 // ABL (diagnostic, wrong results): 1 = no softmax VALU (P := S), 2 = no MFMA, 3 = staging + barriers only
 template <int DHP, int QT, int ABL = 0>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention_kernel(const AttnParams p) {
     using T = AttTile<DHP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;

@@ -634,8 +634,10 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
     WS(tproj, float, (size_t)c.B * tproj_.N);
     LAUNCH(launch_timestep_sinusoid(timesteps, tsin, c.B, C0, c.s));
     LAUNCH(launch_gemv(tsin, time1_.w, time1_.b, e1, c.B, temb, C0, 0, 1, c.s));
-    LAUNCH(launch_gemv(e1, time2_.w, time2_.b, emb, c.B, temb, temb, 0, 0, c.s));
-    LAUNCH(launch_gemv(emb, tproj_.w, tproj_.b, tproj, c.B, tproj_.N, temb, 1, 0, c.s));
+    // `emb` only ever reaches the resnets through SiLU (resnet.py:186): apply it once here instead of once per
+    // output feature inside the stacked projection
+    LAUNCH(launch_gemv(e1, time2_.w, time2_.b, emb, c.B, temb, temb, 0, 1, c.s));
+    LAUNCH(launch_gemv(emb, tproj_.w, tproj_.b, tproj, c.B, tproj_.N, temb, 0, 0, c.s));
 
     std::vector<int> Hs(L), Ws(L);
     for (int l = 0; l < L; ++l) {

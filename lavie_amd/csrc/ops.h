@@ -41,6 +41,7 @@ struct TemporalParams {
     float scale;
 };
 int launch_temporal_attention(const TemporalParams& p, hipStream_t stream);
+void temporal_set_budget(int bytes);   // tuning knob: LDS bytes per workgroup
 
 // ---- elementwise.hip
 int launch_timestep_sinusoid(const float* t, float* out, int B, int dim, hipStream_t stream);

@@ -219,6 +219,10 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
     }
 }
 
+// LDS budget per workgroup for the three staged arrays: smaller tiles = more workgroups per CU in flight
+static int g_temporal_budget = 33000;   // measured best of 17/33/65 KB: ~4 workgroups per CU (profiles/r01_notes)
+void temporal_set_budget(int bytes) { g_temporal_budget = bytes; }
+
 int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
     LAVIE_CHECK(p.F >= 1 && p.F <= 64, "temporal attention: F=%d unsupported (1..64)", p.F);
     LAVIE_CHECK(p.dh % 8 == 0 && p.dh <= 160 && p.rot_dim <= 32 && p.rot_dim <= p.dh && p.rot_dim % 2 == 0,
@@ -232,7 +236,7 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
     // pick (HG, PT): largest tile whose three LDS arrays stay under ~64 KiB (2 workgroups per CU)
     TemporalGeom gm;
     gm.HG = p.heads;
-    const int budget = 64 * 1024 + 1024;
+    const int budget = g_temporal_budget;
     while (gm.HG > 1 && 3 * FP * (gm.HG * p.dh * 2 + 32) > budget && gm.HG % 2 == 0) gm.HG /= 2;
     LAVIE_CHECK((gm.HG * p.dh * 2) % 64 == 0, "temporal attention: head-group row must be a multiple of 64 B");
     gm.RL = gm.HG * p.dh;
