@@ -138,7 +138,6 @@ int lavie_temporal_attention_f16(const void* qkv, int ld, void* o, int ldo, int 
                                  const float* bias, const float* rot_cos, const float* rot_sin, int rot_dim, float scale,
                                  void* stream) {
     LAVIE_CHECK(qkv && o && bias && rot_cos && rot_sin, "temporal attention: null tensor");
-    LAVIE_CHECK(F <= 16, "temporal attention: F=%d > 16 not enabled in this build", F);
     TemporalParams t;
     t.qkv = H(qkv); t.ld = ld; t.o = H(o); t.ldo = ldo; t.B = B; t.F = F; t.D = D; t.heads = heads; t.dh = dh;
     t.bias = bias; t.rot_cos = rot_cos; t.rot_sin = rot_sin; t.rot_dim = rot_dim; t.scale = scale;

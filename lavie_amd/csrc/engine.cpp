@@ -713,8 +713,8 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
 }
 
 static int check_shape(const lavie_unet_config& cfg, int B, int F, int H, int W, int ctx_len) {
-    LAVIE_CHECK(B >= 1 && B <= 8 && F >= 1 && F <= 16 && H >= 1 && W >= 1 && ctx_len >= 1,
-                "shape: B=%d (1..8) F=%d (1..16) H=%d W=%d ctx_len=%d unsupported", B, F, H, W, ctx_len);
+    LAVIE_CHECK(B >= 1 && B <= 8 && F >= 1 && F <= 64 && H >= 1 && W >= 1 && ctx_len >= 1,
+                "shape: B=%d (1..8) F=%d (1..64) H=%d W=%d ctx_len=%d unsupported", B, F, H, W, ctx_len);
     const int div = 1 << (cfg.num_levels - 1);
     LAVIE_CHECK(H % div == 0 && W % div == 0, "shape: H=%d W=%d must be multiples of %d (unet.py:393-401 upsample-size "
                 "forwarding is not implemented)", H, W, div);
@@ -773,7 +773,7 @@ int UNet::transformer_forward(const char* prefix, half_t* x, const half_t* ctx, 
     const TransformerW* t = nullptr;
     for (const TransformerW& cand : transformers_) if (cand.prefix == prefix) t = &cand;
     LAVIE_CHECK(t != nullptr, "transformer_forward: no Transformer3DModel with prefix '%s'", prefix);
-    LAVIE_CHECK(F >= 1 && F <= 16, "transformer_forward: F=%d unsupported", F);
+    LAVIE_CHECK(F >= 1 && F <= 64, "transformer_forward: F=%d unsupported", F);
     RUN(ensure_tables(F, stream));
     DeviceArena local;
     const size_t T = (size_t)B * F * H * W;

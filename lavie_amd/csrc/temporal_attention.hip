@@ -233,14 +233,20 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
     ProfileScope prof(KC_TEMPORAL, stream, 4.0 * tok * p.F * width, 4.0 * tok * width * 2.0);
     const int NT = cdiv(p.F, 16) <= 1 ? 1 : 4;
     const int FP = NT * 16;
-    // pick (HG, PT): largest tile whose three LDS arrays stay under ~64 KiB (2 workgroups per CU)
+    // pick (HG, PT): the largest tile whose three LDS arrays stay under the budget.  Rows are padded to 32 B x odd
+    // (conflict-free ds_read_b128 over 16 frames and ds_read_b64_tr_b16 over 8 keys, see attention.hip).
     TemporalGeom gm;
+    auto row_stride = [&](int hg) {
+        int rs = hg * p.dh * 2 + 32;
+        if (((rs / 32) & 1) == 0) rs += 32;
+        return rs;
+    };
+    const int budget = g_temporal_budget > 3 * FP * 256 ? g_temporal_budget : 3 * FP * 256;
     gm.HG = p.heads;
-    const int budget = g_temporal_budget;
-    while (gm.HG > 1 && 3 * FP * (gm.HG * p.dh * 2 + 32) > budget && gm.HG % 2 == 0) gm.HG /= 2;
-    LAVIE_CHECK((gm.HG * p.dh * 2) % 64 == 0, "temporal attention: head-group row must be a multiple of 64 B");
+    while (gm.HG > 2 && gm.HG % 2 == 0 && 3 * FP * row_stride(gm.HG) > budget) gm.HG /= 2;
+    LAVIE_CHECK((gm.HG * p.dh * 2) % 32 == 0, "temporal attention: head-group row (%d heads x %d) must be a multiple of 32 B", gm.HG, p.dh);
     gm.RL = gm.HG * p.dh;
-    gm.RS = gm.RL * 2 + 32;
+    gm.RS = row_stride(gm.HG);
     gm.PT = budget / (3 * FP * gm.RS);
     if (gm.PT < 1) gm.PT = 1;
     if (gm.PT > 4) gm.PT = 4;

@@ -118,12 +118,11 @@ def test_resnet_golden_full_width_seams():
 
 
 def test_temporal_attention_golden():
-    """reference TemporalAttention fixtures (F = 16) through LN-free projections + the temporal core kernel."""
+    """reference TemporalAttention fixtures (F = 16 and the interpolation model's F = 61) through the projection GEMMs +
+    the temporal core kernel."""
     from lavie_amd import ops
     from oracle import unet_fp32 as O
     for c in G.load("temporal_attention.pt")["cases"]:
-        if c["frames"] > 16:
-            continue                                  # F = 61 belongs to the interpolation model (next row f1)
         sd = G.synth16(c["shapes"], c["seed"])
         x = c["x"].float()                            # [(b d), f, C] with b = 1
         nseq, f, ch = x.shape
@@ -186,6 +185,18 @@ def test_whole_unet_other_shapes(small):
         ref = O.unet_forward(sd, x.float(), t, ctx.float(), ocfg_small())
         got = net(x.cuda(), t.cuda(), encoder_hidden_states=ctx.cuda()).sample
         assert rel_l2(got, ref) < TOL_UNET
+
+
+def test_whole_unet_long_clip(small):
+    """F = 24 frames (> 16): the 64-frame temporal tile path inside the whole UNet."""
+    from oracle import unet_fp32 as O
+    net, sd = small
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 4, 24, 8, 8, generator=g).half()
+    ctx = torch.randn(1, 77, 128, generator=g).half()
+    ref = O.unet_forward(sd, x.float(), 321, ctx.float(), ocfg_small())
+    got = net(x.cuda(), 321, encoder_hidden_states=ctx.cuda()).sample
+    assert rel_l2(got, ref) < TOL_UNET
 
 
 def test_unet_rejects_bad_shapes(small):

@@ -231,7 +231,8 @@ def test_cross_attention_text(ops, b, f, d, c):
     assert rel_l2(got, ref) < TOL_OP
 
 
-@pytest.mark.parametrize("b,f,d,c", [(2, 16, 24, 320), (1, 16, 10, 640), (2, 16, 5, 1280), (1, 4, 7, 320), (1, 13, 3, 256)])
+@pytest.mark.parametrize("b,f,d,c", [(2, 16, 24, 320), (1, 16, 10, 640), (2, 16, 5, 1280), (1, 4, 7, 320), (1, 13, 3, 256),
+                                     (1, 61, 9, 320), (2, 33, 4, 640), (1, 61, 3, 1280), (1, 17, 5, 256)])
 def test_temporal_attention(ops, b, f, d, c):
     from oracle import unet_fp32 as O
     g = gen(f * d + c)
