@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3, help="timed video-latents per GPU")
     ap.add_argument("--warmup", type=int, default=1, help="untimed video-latents per GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample-frames", type=int, default=1, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample-frames", type=int, default=8, help="frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = cgroup/affinity share)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline instrumentation")
     ap.add_argument("--ddpm-steps", type=int, default=DDPM_STEPS, help=argparse.SUPPRESS)   # debugging only

@@ -155,6 +155,9 @@ int lavie_unet_set_param(lavie_unet_t h, const char* name, const void* data_f16,
 int lavie_unet_finalize(lavie_unet_t h, void* stream);
 /* Size the activation workspace for inputs up to [B, *, F, H, W] (allocates; not stream-ordered). */
 int lavie_unet_prepare(lavie_unet_t h, int B, int F, int H, int W, int ctx_len);
+/* A/B switch (default on): fold every LayerNorm of the transformer blocks into the epilogues of the GEMM that
+ * produces its input (row statistics) and the GEMM that consumes its output (gamma folded into the weights). */
+int lavie_unet_set_ln_fold(lavie_unet_t h, int on);
 long long lavie_unet_weight_bytes(lavie_unet_t h);
 long long lavie_unet_workspace_bytes(lavie_unet_t h);
 /* sample [B, Cin, F, H, W] fp16 (NCFHW, as the reference passes it), timesteps [B] fp32,

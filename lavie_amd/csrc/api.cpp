@@ -216,6 +216,12 @@ int lavie_unet_prepare(lavie_unet_t h, int B, int F, int Hh, int W, int ctx_len)
     return h->net.prepare(B, F, Hh, W, ctx_len);
 }
 
+int lavie_unet_set_ln_fold(lavie_unet_t h, int on) {
+    LAVIE_CHECK(h, "set_ln_fold: null handle");
+    h->net.set_ln_fold(on != 0);
+    return 0;
+}
+
 long long lavie_unet_weight_bytes(lavie_unet_t h) { return h ? h->net.weight_bytes() : -1; }
 long long lavie_unet_workspace_bytes(lavie_unet_t h) { return h ? h->net.workspace_bytes() : -1; }
 

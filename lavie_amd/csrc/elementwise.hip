@@ -365,6 +365,49 @@ int launch_add_f16_to_f32(const half_t* a, const half_t* b, float* dst, int64_t 
     return 0;
 }
 
+// LayerNorm folding: W'[n, k] = fp16(W[n, k] * gamma[k]);  s[n] = sum_k W'[n, k];
+// b'[n] = sum_k beta[k] * W[n, k] (+ bias[n]).  One wave per output row.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const half_t* __restrict__ W, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const half_t* __restrict__ bias,
+                                                     half_t* __restrict__ Wout, float* __restrict__ s_out,
+                                                     float* __restrict__ b_out, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float s = 0.f, b = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)W[(size_t)n * K + k];
+        const half_t wf = (half_t)(w * gamma[k]);
+        Wout[(size_t)n * K + k] = wf;
+        s += (float)wf;
+        b += beta[k] * w;
+    }
+    s = wave_sum(s);
+    b = wave_sum(b);
+    if (lane == 0) {
+        s_out[n] = s;
+        b_out[n] = b + (bias ? (float)bias[n] : 0.f);
+    }
+}
+
+int launch_ln_fold(const half_t* W, const float* gamma, const float* beta, const half_t* bias, half_t* Wout, float* s_out,
+                   float* b_out, int N, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, stream, W, gamma, beta, bias, Wout, s_out, b_out, N, K);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void pack_geglu_vec_kernel(const float* __restrict__ in, float* __restrict__ out, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) out[n] = in[geglu_src_row(n, N)];
+}
+
+int launch_pack_geglu_vec(const float* in, float* out, int N, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_geglu_vec_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, in, out, N);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
 // conv_in weights [Cout][Cin][3][3] -> [(ky*3+kx)*Cin + ci][Cout]
 __global__ void pack_conv_in_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

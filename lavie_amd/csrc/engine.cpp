@@ -327,6 +327,30 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
         RUN(launch_pack_geglu_bias(bias, t->ff1.b, 8 * C, s));
     }
     RUN(pack_linear(b + ".ff.net.2", C, 4 * C, true, &t->ff2, s));
+
+    // LayerNorm-folded projections (norm1 -> attn1 qkv, norm2 -> attn2 q, norm_temp -> attn_temp qkv, norm3 -> GEGLU)
+    auto fold = [&](const half_t* W, const NormW& ln, const half_t* bias, int N, half_t** Wf, float** sv, float** bv) -> int {
+        WALLOC(*Wf, half_t, (size_t)N * C);
+        WALLOC(*sv, float, N);
+        WALLOC(*bv, float, N);
+        return launch_ln_fold(W, ln.g, ln.b, bias, *Wf, *sv, *bv, N, C, s);
+    };
+    RUN(fold(t->wqkv1, t->ln1, nullptr, 3 * C, &t->f_qkv1, &t->s_qkv1, &t->b_qkv1));
+    RUN(fold(t->wq2, t->ln2, nullptr, C, &t->f_q2, &t->s_q2, &t->b_q2));
+    RUN(fold(t->wqkvt, t->lnt, nullptr, 3 * C, &t->f_qkvt, &t->s_qkvt, &t->b_qkvt));
+    {
+        // GEGLU: fold in the checkpoint's row order, then apply the value/gate interleave to W', s and b'
+        const half_t* w = given(b + ".ff.net.0.proj.weight");
+        const half_t* bias = given(b + ".ff.net.0.proj.bias");
+        half_t* tmpW; float* tmps; float* tmpb;
+        RUN(fold(w, t->ln3, bias, 8 * C, &tmpW, &tmps, &tmpb));
+        WALLOC(t->f_ff1, half_t, (size_t)8 * C * C);
+        WALLOC(t->s_ff1, float, 8 * C);
+        WALLOC(t->b_ff1, float, 8 * C);
+        RUN(launch_pack_geglu_rows(tmpW, t->f_ff1, 8 * C, C, s));
+        RUN(launch_pack_geglu_vec(tmps, t->s_ff1, 8 * C, s));
+        RUN(launch_pack_geglu_vec(tmpb, t->b_ff1, 8 * C, s));
+    }
     return 0;
 }
 
@@ -432,10 +456,22 @@ struct FwdCtx {
     LAVIE_CHECK(var != nullptr, "workspace exhausted: call lavie_unet_prepare for this shape (needed %zu more B)", \
                 (size_t)(count) * sizeof(type))
 
+struct LnFold {            // consumer side of a folded LayerNorm
+    const float* stats;    // [M, 2] (mean, rstd) of the rows
+    const float* s;        // row sums of the folded weights
+};
+struct RowStat {           // producer side: partials [M, slots, 2] -> (mean, rstd) [M, 2]
+    float* partials;
+    float* mean_rstd;
+    int slots;
+};
+
 static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const float* bias, int N, int K, const half_t* R,
-                  half_t* C, int ldc, int M, int epilogue = EPI_LINEAR) {
+                  half_t* C, int ldc, int M, int epilogue = EPI_LINEAR, const LnFold* fold = nullptr,
+                  const RowStat* rowstat = nullptr) {
+    const bool unsplit = fold != nullptr || rowstat != nullptr;
     if (c.dry) {   // plan the split-K slab so that prepare() sizes the workspace for it
-        const int s = igemm_plan_splits(M, N, K / IGEMM_BK, epilogue);
+        const int s = unsplit ? 1 : igemm_plan_splits(M, N, K / IGEMM_BK, epilogue);
         if (s > 1) {
             const size_t mark = c.ws->mark();
             (void)c.ws->alloc((size_t)s * M * N * sizeof(float));
@@ -448,13 +484,16 @@ static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const fl
     p.A = A; p.lda = lda; p.W = W; p.ldw = K; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldc;
     p.M = M; p.N = N; p.nk = K / IGEMM_BK;
     LAVIE_CHECK(K % IGEMM_BK == 0, "linear: K=%d must be a multiple of %d", K, IGEMM_BK);
-    p.splits = igemm_plan_splits(M, N, p.nk, epilogue);
+    p.splits = unsplit ? 1 : igemm_plan_splits(M, N, p.nk, epilogue);
+    p.rowstat_out = rowstat ? rowstat->partials : nullptr;
+    if (fold) { p.ln_stats = fold->stats; p.ln_s = fold->s; }
     const size_t mark = c.ws->mark();
     if (p.splits > 1) {
         p.slab = (float*)c.ws->alloc((size_t)p.splits * M * N * sizeof(float));
         LAVIE_CHECK(p.slab != nullptr, "workspace exhausted (split-K slab)");
     }
-    const int rc = launch_igemm(p, false, epilogue, c.s);
+    int rc = launch_igemm(p, false, epilogue, c.s);
+    if (rc == 0 && rowstat) rc = launch_rowstat_finalize(rowstat->partials, rowstat->slots, M, N, 1e-5f, rowstat->mean_rstd, c.s);
     c.ws->release(mark);
     return rc;
 }
@@ -559,22 +598,47 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
 
     // per-frame GroupNorm (eps 1e-6) + 1x1 proj_in (attention.py:369-373)
     LAUNCH(launch_group_norm(x, C, nullptr, 0, NI, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s));
-    RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, T));
+    // LayerNorm folding: the GEMM that produces the residual stream `tx` also emits per-row (sum, sum^2) partials of
+    // its fp16 output, and the projection that consumes LN(tx) runs on raw `tx` with gamma folded into its weights,
+    // finishing rstd * (acc - mean * s) + b' in its epilogue — no LayerNorm kernel, no normalised copy in HBM.
+    const bool fold = ln_fold_;
+    LnFold lf{nullptr, nullptr};
+    RowStat rsd{nullptr, nullptr, C / igemm_rowstat_cols(T, C)};
+    const RowStat* rowstat = nullptr;
+    if (fold) {
+        WS(rsp, float, (size_t)T * (C / 32) * 2);
+        WS(rsm, float, (size_t)T * 2);
+        rsd.partials = rsp;
+        rsd.mean_rstd = rsm;
+        lf.stats = rsm;
+        rowstat = &rsd;
+    }
+    RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, T, EPI_LINEAR, nullptr, rowstat));
 
     // spatial self-attention (attention.py:513-522)
-    LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, T, C, 1e-5f, c.s));
-    RUN(linear(c, ln, C, t.wqkv1, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+    if (fold) {
+        lf.s = t.s_qkv1;
+        RUN(linear(c, tx, C, t.f_qkv1, t.b_qkv1, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
+    } else {
+        LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, T, C, 1e-5f, c.s));
+        RUN(linear(c, ln, C, t.wqkv1, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+    }
     if (!c.dry) {
         AttnParams a;
         a.q = wide; a.ldq = 3 * C; a.k = wide + C; a.ldk = 3 * C; a.v = wide + 2 * C; a.ldv = 3 * C;
         a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = D; a.heads = heads; a.dh = dh; a.kv_batch_div = 1; a.scale = scale;
         RUN(launch_attention(a, c.s));
     }
-    RUN(linear(c, att, C, t.o1.w, t.o1.b, C, C, tx, tx, C, T));
+    RUN(linear(c, att, C, t.o1.w, t.o1.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
 
     // text cross-attention (attention.py:524-534); K/V once per video instead of once per frame (364)
-    LAUNCH(launch_layernorm(tx, t.ln2.g, t.ln2.b, ln, T, C, 1e-5f, c.s));
-    RUN(linear(c, ln, C, t.wq2, nullptr, C, C, nullptr, wide, C, T));
+    if (fold) {
+        lf.s = t.s_q2;
+        RUN(linear(c, tx, C, t.f_q2, t.b_q2, C, C, nullptr, wide, C, T, EPI_LINEAR, &lf));
+    } else {
+        LAUNCH(launch_layernorm(tx, t.ln2.g, t.ln2.b, ln, T, C, 1e-5f, c.s));
+        RUN(linear(c, ln, C, t.wq2, nullptr, C, C, nullptr, wide, C, T));
+    }
     RUN(linear(c, ctx, X, t.wkv2, nullptr, 2 * C, X, nullptr, kv2, 2 * C, c.B * c.ctx_len));
     if (!c.dry) {
         AttnParams a;
@@ -582,22 +646,32 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = c.ctx_len; a.heads = heads; a.dh = dh; a.kv_batch_div = c.F; a.scale = scale;
         RUN(launch_attention(a, c.s));
     }
-    RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T));
+    RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
 
     // temporal self-attention over frames, tokens stay in (b f) d order (attention.py:548-555)
-    LAUNCH(launch_layernorm(tx, t.lnt.g, t.lnt.b, ln, T, C, 1e-5f, c.s));
-    RUN(linear(c, ln, C, t.wqkvt, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+    if (fold) {
+        lf.s = t.s_qkvt;
+        RUN(linear(c, tx, C, t.f_qkvt, t.b_qkvt, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
+    } else {
+        LAUNCH(launch_layernorm(tx, t.lnt.g, t.lnt.b, ln, T, C, 1e-5f, c.s));
+        RUN(linear(c, ln, C, t.wqkvt, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+    }
     if (!c.dry) {
         TemporalParams tp;
         tp.qkv = wide; tp.ld = 3 * C; tp.o = att; tp.ldo = C; tp.B = c.B; tp.F = c.F; tp.D = D; tp.heads = heads; tp.dh = dh;
         tp.bias = relbias_[ti]; tp.rot_cos = rot_cos_; tp.rot_sin = rot_sin_; tp.rot_dim = cfg_.rotary_dim; tp.scale = scale;
         RUN(launch_temporal_attention(tp, c.s));
     }
-    RUN(linear(c, att, C, t.ot.w, t.ot.b, C, C, tx, tx, C, T));
+    RUN(linear(c, att, C, t.ot.w, t.ot.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
 
     // GEGLU feed-forward (attention.py:558)
-    LAUNCH(launch_layernorm(tx, t.ln3.g, t.ln3.b, ln, T, C, 1e-5f, c.s));
-    RUN(linear(c, ln, C, t.ff1.w, t.ff1.b, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU));
+    if (fold) {
+        lf.s = t.s_ff1;
+        RUN(linear(c, tx, C, t.f_ff1, t.b_ff1, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU, &lf));
+    } else {
+        LAUNCH(launch_layernorm(tx, t.ln3.g, t.ln3.b, ln, T, C, 1e-5f, c.s));
+        RUN(linear(c, ln, C, t.ff1.w, t.ff1.b, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU));
+    }
     RUN(linear(c, wide, 4 * C, t.ff2.w, t.ff2.b, C, 4 * C, tx, tx, C, T));
 
     // 1x1 proj_out + residual, in place on the block input (attention.py:394-401)

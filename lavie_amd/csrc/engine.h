@@ -61,6 +61,11 @@ struct TransformerW {
     half_t* wqkvt = nullptr; LinW ot;
     half_t* relemb = nullptr;                       // [buckets][heads] fp16 (state-dict tensor)
     LinW ff1, ff2;                                  // ff1 in GEGLU-interleaved row order
+    // LayerNorm-folded copies of the four projections that consume a LayerNorm (W * gamma, row sums, W beta + bias)
+    half_t* f_qkv1 = nullptr; float* s_qkv1 = nullptr; float* b_qkv1 = nullptr;
+    half_t* f_q2 = nullptr; float* s_q2 = nullptr; float* b_q2 = nullptr;
+    half_t* f_qkvt = nullptr; float* s_qkvt = nullptr; float* b_qkvt = nullptr;
+    half_t* f_ff1 = nullptr; float* s_ff1 = nullptr; float* b_ff1 = nullptr;
 };
 
 struct SamplerW { half_t* w = nullptr; float* b = nullptr; int C = 0; };
@@ -84,6 +89,7 @@ public:
                             hipStream_t stream);
     long long weight_bytes() const { return (long long)weights_.total_bytes(); }
     long long workspace_bytes() const { return (long long)ws_.total_bytes(); }
+    void set_ln_fold(bool on) { ln_fold_ = on; }
 
 private:
     void build_param_list();
@@ -106,6 +112,7 @@ private:
     std::unordered_map<std::string, size_t> index_;
     std::vector<const half_t*> given_;
     bool finalized_ = false;
+    bool ln_fold_ = true;                           // LayerNorm folded into the producer / consumer GEMM epilogues
 
     DeviceArena weights_, ws_;
     // packed model

@@ -35,6 +35,12 @@ struct IgemmParams {
     const half_t* R;      // residual [M, N] (ldr) or nullptr; may alias C
     int ldr;
     int M, N, nk;         // nk = total number of K-tiles
+    // LayerNorm folding: a producer GEMM writes per-row partial (sum, sum of squares) of its fp16 output,
+    // one pair per 16*NT-column wave tile: rowstat_out[m * rowstat_slots + slot]; the consumer GEMM runs on the RAW
+    // rows with gamma folded into W and finishes  y = rstd_m (acc - mean_m s_n) + bias_n  in its epilogue.
+    float* rowstat_out;        // [M, N / rowstat_cols, 2] or nullptr (EPI_LINEAR, splits == 1 only)
+    const float* ln_stats;     // [M, 2] (mean, rstd) of the A rows (launch_rowstat_finalize), or nullptr
+    const float* ln_s;         // [N]: s_n = sum_k W'[n, k]
     int splits;           // split-K factor (1 = none); > 1 needs `slab`
     float* slab;          // [splits, M, N] fp32 partial sums
     // Gather geometry (GATHER = true): output pixel grid [NI, Ho, Wo], source grid [NI, Hi, Wi],
@@ -55,6 +61,10 @@ int launch_igemm_big(const IgemmParams& p, bool gather, hipStream_t stream);
 // Split-K factor the launcher would like for this problem (1 = none); slab size = splits * M * N floats.
 int igemm_plan_splits(int M, int N, int nk, int epilogue);
 // 0 = automatic tile choice, 1 = 128-row tiles only, 2 = 256-row tiles whenever N %% 160 == 0 (tests, A/B timing)
+// wave-tile width (16*NT) launch_igemm will pick for a plain, unsplit EPI_LINEAR GEMM: the row-statistics slot width
+int igemm_rowstat_cols(int M, int N);
+// partials [M, slots, 2] (sum, sum of squares over `row_len` values per row) -> out [M, 2] = (mean, rstd); fixed order
+int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len, float eps, float* out, hipStream_t stream);
 void igemm_force_tile(int mode);
 void igemm_force_splits(int s);   // 0 = automatic
 

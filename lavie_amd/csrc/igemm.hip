@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
 
 // Split-K factor for an under-filled grid.  The 128-row tiles run 2 workgroups per CU (512 slots); a grid of
 // `blocks` tiles takes ceil(blocks*S/512) rounds of (nk/S + fixed) K-steps plus a reduce pass over S slabs.
+static int g_force_tile = 0;   // 0 auto, 1 128-row tiles with the widest N, 2 256-row experimental kernel (tests / A-B timing)
 static bool g_big_auto = false;    // flipped on once the big kernel wins on the shapes above
 static int g_force_splits = 0;
 void igemm_force_splits(int s) { g_force_splits = s; }
@@ -339,7 +340,6 @@ static bool igemm_prefers_big(int M, int N, int nk, int splits) {
     return g_big_auto && blocks >= 256 && nk >= 8;
 }
 
-static int g_force_tile = 0;   // 0 auto, 1 small tiles only, 2 big tiles whenever N allows (tests / A-B timing)
 
 template <int WM, int WN, int MT, int NT, int NSTAGE, bool GATHER, int EPI, int ABL = 0>
 static int launch_tile(const IgemmParams& p, hipStream_t stream) {
@@ -365,6 +365,45 @@ static int launch_tile(const IgemmParams& p, hipStream_t stream) {
 
 #define RUN_BIG(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 
+// Tile width by grid quantisation: the 4-wave tiles run 2 workgroups per CU (512 slots per round); a narrower
+// tile is a little less efficient per flop (exponent 0.9) but can save a whole round on short grids.
+static int igemm_pick_bn(int M, int N, int splits) {
+    double best = 1e30;
+    int bn = 0;
+    const int cand[3] = {160, 128, 64};
+    for (int i = 0; i < 3; ++i) {
+        if (N % cand[i] != 0) continue;
+        const long blocks = (long)cdiv(M, 128) * (N / cand[i]) * splits;
+        const double cost = (double)((blocks + 511) / 512) * pow(cand[i] / 160.0, 0.9);
+        if (cost < best * 0.97) { best = cost; bn = cand[i]; }
+    }
+    if (((g_force_tile & 0xF) != 0 || g_force_tile >= 0x10) && N % 160 == 0) bn = 160;   // forced modes: widest
+    return bn;
+}
+
+__global__ void rowstat_finalize_kernel(const float* __restrict__ partials, int slots, int M, float inv_len, float eps,
+                                        float* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* st = partials + (size_t)m * slots * 2;
+    float sum = 0.f, sq = 0.f;
+    for (int j = 0; j < slots; ++j) { sum += st[2 * j]; sq += st[2 * j + 1]; }
+    const float mean = sum * inv_len;
+    out[(size_t)m * 2] = mean;
+    out[(size_t)m * 2 + 1] = rsqrtf(fmaxf(sq * inv_len - mean * mean, 0.f) + eps);
+}
+
+int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len, float eps, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(rowstat_finalize_kernel, dim3(cdiv(M, 256)), dim3(256), 0, stream, partials, slots, M,
+                       1.0f / (float)row_len, eps, out);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+// Columns per row-statistics slot (= the wave tile width 16*NT) launch_igemm uses for a plain, unsplit EPI_LINEAR
+// GEMM; two waves share a tile's columns.
+int igemm_rowstat_cols(int M, int N) { return igemm_pick_bn(M, N, 1) / 2; }
+
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream) {
     LAVIE_CHECK(p.M > 0 && p.N > 0 && p.nk > 0, "igemm: empty problem M=%d N=%d nk=%d", p.M, p.N, p.nk);
     const double K = (double)p.nk * IGEMM_BK;
@@ -372,6 +411,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     ProfileScope prof(gather ? KC_CONV3X3 : KC_LINEAR, stream, 2.0 * p.M * p.N * K,
                       2.0 * ((double)p.M * K / (gather ? 9.0 : 1.0) + (double)p.N * K + (double)p.M * p.N));
     LAVIE_CHECK(p.N % 4 == 0 && p.ldc % 4 == 0, "igemm: N and ldc must be multiples of 4");
+    LAVIE_CHECK(!(p.rowstat_out || p.ln_stats) || (p.splits == 1 && !gather), "igemm: LayerNorm folding needs a plain, unsplit GEMM");
     LAVIE_CHECK(p.splits >= 1 && p.splits <= p.nk && (p.splits == 1 || (p.slab && epilogue == EPI_LINEAR)),
                 "igemm: bad split-K setup (splits=%d)", p.splits);
     // Tile choice.  "big": 256x160, 8 waves, 3 LDS stages (1 workgroup per CU, 2 waves per SIMD) — enough
@@ -387,20 +427,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         if (big) return launch_tile<4, 2, 4, 4, 3, false, EPI_GEGLU>(p, stream);
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
     }
-    // Tile width by grid quantisation: the 4-wave tiles run 2 workgroups per CU (512 slots per round); a narrower
-    // tile is a little less efficient per flop (exponent 0.9) but can save a whole round on short grids.
-    int bn = 0;
-    {
-        double best = 1e30;
-        const int cand[3] = {160, 128, 64};
-        for (int i = 0; i < 3; ++i) {
-            if (p.N % cand[i] != 0) continue;
-            const long blocks = (long)cdiv(p.M, 128) * (p.N / cand[i]) * p.splits;
-            const double cost = (double)((blocks + 511) / 512) * pow(cand[i] / 160.0, 0.9);
-            if (cost < best * 0.97) { best = cost; bn = cand[i]; }
-        }
-        if ((g_force_tile & 0xF) != 0 || g_force_tile >= 0x10) bn = p.N % 160 == 0 ? 160 : bn;   // forced modes: widest
-    }
+    const int bn = igemm_pick_bn(p.M, p.N, p.splits);
     LAVIE_CHECK(bn != 0, "igemm: N=%d is not a multiple of 64", p.N);
     if (bn == 160) {
         if (g_force_tile >= 0x10 && gather) {          // diagnostic ablations of the main conv kernel

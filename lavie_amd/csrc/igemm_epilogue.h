@@ -11,11 +11,30 @@ namespace lavie {
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int mrow, int ncol, int nwave0,
                                                int lane, int split) {
+    // ---- folded LayerNorm of the A rows: acc <- rstd_m * (acc - mean_m * s_n); the folded bias comes in as p.bias
+    if (p.ln_stats) {
+        f32x4 sv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sv[nt] = *reinterpret_cast<const f32x4*>(p.ln_s + ncol + nt * 16);
+        float mean[MT], rstd[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mrow + mt * 16;
+            const int mc = m < p.M ? m : p.M - 1;
+            mean[mt] = p.ln_stats[(size_t)mc * 2];
+            rstd[mt] = p.ln_stats[(size_t)mc * 2 + 1];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = (acc[nt][mt] - mean[mt] * sv[nt]) * rstd[mt];
+    }
     // ---- epilogue: lane holds channels n..n+3 of token m for every (nt, mt) ----
     // Which optional operands exist is decided ONCE (wave-uniform) and the body is instantiated per
     // combination: per-element "if (ptr) load" makes hipcc wait vmcnt(0) after every load (guide §5, trap (c)).
     auto epilogue = [&](auto has_bias, auto has_b2, auto has_res) {
         constexpr bool BIAS = decltype(has_bias)::value, B2 = decltype(has_b2)::value, RES = decltype(has_res)::value;
+        const bool rowstat = p.rowstat_out != nullptr;
         f32x4 bv[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -27,6 +46,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = mrow + mt * 16;
                 const int mc = m < p.M ? m : p.M - 1;              // clamp: loads stay in bounds, stores are predicated
+                float rs_sum = 0.f, rs_sq = 0.f;
                 f32x4 b2v[NT];
                 half4_t rv[NT];
 #pragma unroll
@@ -45,6 +65,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                     }
                     const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                     if (m < p.M) *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + ncol + nt * 16) = o;
+                    if (rowstat) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; rs_sum += f; rs_sq += f * f; }
+                    }
+                }
+                if (rowstat) {
+                    // this wave's 16*NT columns of row m: fold the four 16-lane groups, one pair per (row, wave tile)
+                    rs_sum += __shfl_xor(rs_sum, 16, 64); rs_sq += __shfl_xor(rs_sq, 16, 64);
+                    rs_sum += __shfl_xor(rs_sum, 32, 64); rs_sq += __shfl_xor(rs_sq, 32, 64);
+                    if (m < p.M && (lane >> 4) == 0) {
+                        float* dst = p.rowstat_out + ((size_t)m * (p.N / (NT * 16)) + nwave0 / (NT * 16)) * 2;
+                        dst[0] = rs_sum;
+                        dst[1] = rs_sq;
+                    }
                 }
             }
         } else {

@@ -73,6 +73,10 @@ int launch_pack_geglu_bias(const half_t* b, float* out, int N, hipStream_t strea
 int launch_f16_to_f32(const half_t* src, float* dst, int64_t n, hipStream_t stream);
 int launch_add_f16_to_f32(const half_t* a, const half_t* b, float* dst, int64_t n, hipStream_t stream);
 int launch_pack_conv_in(const half_t* w, half_t* out, int Cout, int Cin, hipStream_t stream);
+// LayerNorm folding: W' = W * gamma (fp16), s = row sums of W', b' = W beta (+ bias)
+int launch_ln_fold(const half_t* W, const float* gamma, const float* beta, const half_t* bias, half_t* Wout, float* s_out,
+                   float* b_out, int N, int K, hipStream_t stream);
+int launch_pack_geglu_vec(const float* in, float* out, int N, hipStream_t stream);
 
 // host-only helper (no GPU): T5-style bucket of (query i, key j), attention.py:681-699
 void relpos_bucket_table(int F, int num_buckets, int max_distance, int* out);

@@ -173,6 +173,26 @@ def test_whole_unet_small_vs_oracle(small, t):
     assert torch.equal(got, got2)                                       # no atomics anywhere: bit-reproducible
 
 
+def test_layernorm_fold_matches_explicit_layernorm(small):
+    """The folded LayerNorm path (default) and the explicit LayerNorm kernels agree, and both match the oracle."""
+    from lavie_amd import _lib
+    from oracle import unet_fp32 as O
+    net, sd = small
+    g = torch.Generator().manual_seed(808)
+    x = torch.randn(2, 4, 16, 8, 8, generator=g).half()
+    ctx = torch.randn(2, 77, 128, generator=g).half()
+    ref = O.unet_forward(sd, x.float(), 640, ctx.float(), ocfg_small())
+    lib, handle = _lib.load(), net.engine_handle()
+    try:
+        _lib.check(lib.lavie_unet_set_ln_fold(handle, 0))
+        explicit = net(x.cuda(), 640, encoder_hidden_states=ctx.cuda()).sample
+    finally:
+        _lib.check(lib.lavie_unet_set_ln_fold(handle, 1))
+    folded = net(x.cuda(), 640, encoder_hidden_states=ctx.cuda()).sample
+    assert rel_l2(explicit, ref) < TOL_UNET and rel_l2(folded, ref) < TOL_UNET
+    assert rel_l2(folded, explicit) < 5e-3
+
+
 def test_whole_unet_other_shapes(small):
     """ragged sizes: F=5, 8x16 latent, batch 1 and 3, 10 context tokens."""
     from oracle import unet_fp32 as O
@@ -214,6 +234,27 @@ def test_whole_unet_full_width_golden(full):
     for t, ref in fx["y"].items():
         got = net(fx["x"].cuda(), int(t), encoder_hidden_states=fx["ctx"].cuda()).sample
         assert rel_l2(got, ref) < TOL_UNET, t
+
+
+def test_full_size_properties(full):
+    """BASELINE.json's full shape (909 M parameters, F=16, latent 40x64) through size-independent properties:
+    bit-reproducibility, batch independence (the CFG batch of two identical halves returns identical halves, and a
+    batch-1 call — different GEMM tile / split-K choices at half the rows — agrees with them), finite outputs."""
+    net, _ = full
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn(1, 4, 16, 40, 64, generator=g).half()
+    c1 = torch.randn(1, 77, 768, generator=g).half()
+    x2, c2 = torch.cat([x1, x1]).cuda(), torch.cat([c1, c1]).cuda()
+    y2 = net(x2, 500, encoder_hidden_states=c2).sample
+    y2b = net(x2, 500, encoder_hidden_states=c2).sample
+    assert torch.equal(y2, y2b)
+    assert torch.isfinite(y2).all()
+    assert torch.equal(y2[0], y2[1])
+    y1 = net(x1.cuda(), 500, encoder_hidden_states=c1.cuda()).sample
+    assert rel_l2(y1[0], y2[0]) < 5e-3
+    # a different timestep / context must change the answer (guards against stale-buffer reuse)
+    y3 = net(x2, 20, encoder_hidden_states=c2).sample
+    assert rel_l2(y3, y2) > 1e-2
 
 
 def test_three_ddpm_steps_golden(full):
