@@ -48,7 +48,7 @@ struct IgemmTile {
 // ABL (diagnostic builds only, results are wrong): 1 = no MFMA, 2 = no global loads after the prologue,
 // 3 = loads + barriers only.  Used by tools/bench_ops.py to find which pipeline paces the loop.
 template <int WM, int WN, int MT, int NT, int NSTAGE, bool GATHER, int EPI, int ABL = 0>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void igemm_kernel(const IgemmParams p) {
     using T = IgemmTile<WM, WN, MT, NT, NSTAGE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -168,20 +168,28 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         }
     }
 
-    // Source pointers of the NEXT tile to be issued are computed one step ahead (prepare), so that the table
-    // lookup and address arithmetic overlap the MFMAs instead of delaying the LDS-DMA issue after the barrier.
+    // Source pointers of the NEXT tile to be issued are computed one step ahead, in two halves: `prepare_read` only
+    // issues the pixel-table LDS reads (together with the fragment reads of the current tile, so their latency is
+    // shared), `prepare_finish` does the address arithmetic and advances the cursor (placed between the two MFMA
+    // blocks of a tile, where the matrix pipe is already fed).  prepare() = both, for the prologue.
     const half_t* nptr[T::AP];
-    auto prepare = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < T::AP; ++i) {
-            if constexpr (GATHER) {
-                const int pv = tab[arow[i] * 9 + (sg.ntaps == 9 ? tap : 4)];
-                nptr[i] = pv >= 0 ? sg.src + (size_t)pv * sg.C + (sg.c0 + cchunk * IGEMM_BK + kofs) : zero_page + kofs;
-            } else {
-                nptr[i] = aptr[i] + t * IGEMM_BK;
-            }
-        }
+    int pv[T::AP];
+    auto prepare_read = [&]() {
         if constexpr (GATHER) {
+            const int tp = sg.ntaps == 9 ? tap : 4;
+#pragma unroll
+            for (int i = 0; i < T::AP; ++i) pv[i] = tab[arow[i] * 9 + tp];
+        }
+    };
+    auto prepare_finish = [&](int t) {
+        if constexpr (GATHER) {
+            // 32-bit element offsets: a source tensor holds < 2^31 halfs (checked by the launcher)
+            const unsigned cofs = (unsigned)(sg.c0 + cchunk * IGEMM_BK + kofs);
+#pragma unroll
+            for (int i = 0; i < T::AP; ++i) {
+                const half_t* inside = sg.src + ((unsigned)pv[i] * (unsigned)sg.C + cofs);
+                nptr[i] = pv[i] >= 0 ? inside : zero_page + kofs;
+            }
             if (tap_major) {                        // diagnostic K order: tap outer, channel slab inner
                 if (++cchunk == sg.nchunks) {
                     cchunk = 0;
@@ -197,8 +205,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
                     if (seg + 1 < nseg) sg = load_seg(++seg);
                 }
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T::AP; ++i) nptr[i] = aptr[i] + t * IGEMM_BK;
         }
     };
+    auto prepare = [&](int t) { prepare_read(); prepare_finish(t); };
     auto issue = [&](int t, int buf) {
         if (ABL == 2 && t > t_begin + 1) return;
         char* base = smem + buf * T::STAGE_BYTES;
@@ -224,30 +236,43 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     const int a_frag = (wm * MT * 16 + frow) * 128;
     const int w_frag = T::BM * 128 + (wn * NT * 16 + frow) * 128;
 
-    auto compute = [&](int buf) {
-        if (ABL == 3) return;
-        const char* base = smem + buf * T::STAGE_BYTES;
+    // Fragment reads are issued for BOTH 32-deep k-steps of a tile before the first MFMA (two register sets), so the
+    // LDS latency is exposed once per K-tile instead of once per fragment group; the LDS-DMA of the next tile is
+    // issued between the reads and the MFMAs, under that latency.
+    auto read_frags = [&](const char* base, int ks, half8_t (&af)[MT], half8_t (&wf)[NT]) {
+        const int slot = ((ks * 4 + fg) ^ fsw) * 16;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = ((ks * 4 + fg) ^ fsw) * 16;
-            half8_t af[MT], wf[NT];
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const half8_t*>(base + a_frag + mt * 16 * 128 + slot);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                af[mt] = *reinterpret_cast<const half8_t*>(base + a_frag + mt * 16 * 128 + slot);
+        for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const half8_t*>(base + w_frag + nt * 16 * 128 + slot);
+    };
+    auto mfma_block = [&](half8_t (&af)[MT], half8_t (&wf)[NT]) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const half8_t*>(base + w_frag + nt * 16 * 128 + slot);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    if constexpr (ABL == 1) {
-                        asm volatile("" ::"v"(wf[nt]), "v"(af[mt]));      // keep the LDS reads alive
-                    } else {
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-                    }
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (ABL == 1) {
+                    asm volatile("" ::"v"(wf[nt]), "v"(af[mt]));      // keep the LDS reads alive
+                } else {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
                 }
+            }
+    };
+    // one K-tile: fragment + table reads -> LDS-DMA issue of a later tile -> MFMAs(k-step 0) -> pointer arithmetic for
+    // the tile after that -> MFMAs(k-step 1)
+    auto tile_step = [&](int buf, auto&& issue_next, int t_prep) {
+        const char* base = smem + buf * T::STAGE_BYTES;
+        half8_t af0[MT], wf0[NT], af1[MT], wf1[NT];
+        if (ABL != 3) {
+            read_frags(base, 0, af0, wf0);
+            read_frags(base, 1, af1, wf1);
         }
+        const bool prep = t_prep < t_end;
+        if (prep) prepare_read();
+        issue_next();
+        if (ABL != 3) mfma_block(af0, wf0);
+        if (prep) prepare_finish(t_prep);
+        if (ABL != 3) mfma_block(af1, wf1);
     };
     if constexpr (NSTAGE == 2) {
         // one tile in flight: loads of tile t+1 run under the MFMAs of tile t
@@ -258,9 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         for (int t = t_begin; t < t_end; ++t) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces of tile t have landed
             __syncthreads();   // ... and everybody else's; the other buffer is no longer being read
-            if (t + 1 < t_end) issue(t + 1, buf ^ 1);
-            if (t + 2 < t_end) prepare(t + 2);
-            compute(buf);
+            tile_step(buf, [&]() { if (t + 1 < t_end) issue(t + 1, buf ^ 1); }, t + 2);
             buf ^= 1;
         }
     } else {
@@ -278,9 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // tile t visible to all; tile t-1's buffer is free
             asm volatile("" ::: "memory");
-            if (t + 2 < t_end) issue(t + 2, buf == 0 ? 2 : buf - 1);
-            if (t + 3 < t_end) prepare(t + 3);
-            compute(buf);
+            tile_step(buf, [&]() { if (t + 2 < t_end) issue(t + 2, buf == 0 ? 2 : buf - 1); }, t + 3);
             buf = buf == 2 ? 0 : buf + 1;
         }
     }
