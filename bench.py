@@ -134,6 +134,8 @@ def main():
     from lavie_amd.scheduling_ddpm import DDPMScheduler
     from lavie_amd.unet import UNet3DConditionModel
     lib = _lib.load()
+    if os.environ.get("LAVIE_FORCE_TILE"):          # A/B timing only (tools/ab_bench.py): GEMM kernel selection override
+        lib.lavie_debug_force_tile(int(os.environ["LAVIE_FORCE_TILE"], 0))
 
     # ---- model: random-init weights of the full architecture (909 M parameters), rank 0 -> RCCL broadcast
     shapes = spec.param_shapes()

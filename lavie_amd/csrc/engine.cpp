@@ -603,7 +603,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     // finishing rstd * (acc - mean * s) + b' in its epilogue — no LayerNorm kernel, no normalised copy in HBM.
     const bool fold = ln_fold_;
     LnFold lf{nullptr, nullptr};
-    RowStat rsd{nullptr, nullptr, C / igemm_rowstat_cols(T, C)};
+    RowStat rsd{nullptr, nullptr, C / igemm_rowstat_cols(T, C, C / IGEMM_BK)};
     const RowStat* rowstat = nullptr;
     if (fold) {
         WS(rsp, float, (size_t)T * (C / 32) * 2);

@@ -330,14 +330,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
 
 // Split-K factor for an under-filled grid.  The 128-row tiles run 2 workgroups per CU (512 slots); a grid of
 // `blocks` tiles takes ceil(blocks*S/512) rounds of (nk/S + fixed) K-steps plus a reduce pass over S slabs.
-static int g_force_tile = 0;   // 0 auto, 1 128-row tiles with the widest N, 2 256-row experimental kernel (tests / A-B timing)
+static int g_force_tile = 0;   // see igemm_force_tile() in igemm.h
 static bool g_big_auto = false;    // flipped on once the big kernel wins on the shapes above
 static int g_force_splits = 0;
 void igemm_force_splits(int s) { g_force_splits = s; }
 
+// ---- 160x320 ping-pong kernel (igemm_pp.hip): when it is used.  Measured on this model's shapes (tools/bench_ops.py
+// pp_splits, check_pp): it is 15-25 % faster than the 128-row kernel whenever its grid quantises onto the 256 CUs
+// (one workgroup per CU) and the K loop is long enough to amortise its 60 KiB prologue; an under-filled grid or a
+// short K loop loses.  Rule: N % 320 == 0, >= 10 K-tiles, the grid's last round at least 85 % full, and with
+// split-K at least 45 K-tiles per split (the fp32 slab round trip must stay small beside the loop).
+static bool pp_fits(int M, int N, int nk, int s) {
+    if (N % 320 != 0 || nk < 10 || s < 1 || s > nk) return false;
+    if (s > 1 && nk / s < 45) return false;
+    const double r = (double)cdiv(M, 160) * (N / 320) * s / 256.0;
+    return r / ceil(r) >= 0.85;
+}
+// split-K factor with which the ping-pong kernel should run this problem, 0 = do not use it
+static int pp_plan(int M, int N, int nk, int epilogue) {
+    if (epilogue != EPI_LINEAR || (g_force_tile & 0xF) == 4 || (g_force_tile & 0xF) == 1 || (g_force_tile & 0xF) == 2) return 0;
+    for (int s = 1; s <= 4; ++s)
+        if (pp_fits(M, N, nk, s)) return s;
+    return 0;
+}
+
 int igemm_plan_splits(int M, int N, int nk, int epilogue) {
     if (epilogue != EPI_LINEAR || N % 64 != 0) return 1;
     if (g_force_splits > 0) return g_force_splits <= nk ? g_force_splits : 1;
+    if (const int s = pp_plan(M, N, nk, epilogue)) return s;
     const long blocks = (long)cdiv(M, 128) * cdiv(N, 160);
     if (blocks >= 1024) return 1;
     double best = 1e30;
@@ -398,7 +418,8 @@ static int igemm_pick_bn(int M, int N, int splits) {
         const double cost = (double)((blocks + 511) / 512) * pow(cand[i] / 160.0, 0.9);
         if (cost < best * 0.97) { best = cost; bn = cand[i]; }
     }
-    if (((g_force_tile & 0xF) != 0 || g_force_tile >= 0x10) && N % 160 == 0) bn = 160;   // forced modes: widest
+    const int lo = g_force_tile & 0xF;
+    if ((lo == 1 || lo == 2 || lo == 3 || g_force_tile >= 0x10) && N % 160 == 0) bn = 160;   // forced modes: widest
     return bn;
 }
 
@@ -423,7 +444,10 @@ int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len
 
 // Columns per row-statistics slot (= the wave tile width 16*NT) launch_igemm uses for a plain, unsplit EPI_LINEAR
 // GEMM; two waves share a tile's columns.
-int igemm_rowstat_cols(int M, int N) { return igemm_pick_bn(M, N, 1) / 2; }
+int igemm_rowstat_cols(int M, int N, int nk) {
+    if ((g_force_tile & 0xF) == 3 ? N % 320 == 0 : (pp_plan(M, N, nk, EPI_LINEAR) == 1)) return 80;   // ping-pong wave tile
+    return igemm_pick_bn(M, N, 1) / 2;
+}
 
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream) {
     LAVIE_CHECK(p.M > 0 && p.N > 0 && p.nk > 0, "igemm: empty problem M=%d N=%d nk=%d", p.M, p.N, p.nk);
@@ -447,6 +471,18 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         LAVIE_CHECK(!gather, "igemm: GEGLU epilogue is only built for plain A rows");
         if (big) return launch_tile<4, 2, 4, 4, 3, false, EPI_GEGLU>(p, stream);
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
+    }
+    // 160x320 ping-pong kernel: forced (mode 3) or whenever the planner's rule holds for this problem at its split factor
+    const bool use_pp = p.N % 320 == 0 && ((g_force_tile & 0xF) == 3 ||
+                                            ((g_force_tile & 0xF) == 0 && pp_fits(p.M, p.N, p.nk, p.splits)));
+    if (use_pp) {
+        RUN_BIG(launch_igemm_pp(p, gather, stream));
+        if (p.splits > 1) {
+            const long total = (long)p.M * (p.N / 4);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+            LAVIE_HIP(hipGetLastError());
+        }
+        return 0;
     }
     const int bn = igemm_pick_bn(p.M, p.N, p.splits);
     LAVIE_CHECK(bn != 0, "igemm: N=%d is not a multiple of 64", p.N);
@@ -489,6 +525,11 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
 }
 
 void igemm_big_ablate(int a);
-void igemm_force_tile(int mode) { g_force_tile = mode; igemm_big_ablate((mode & 0xF) == 2 ? mode >> 4 : 0); }
+void igemm_pp_ablate(int a);
+void igemm_force_tile(int mode) {
+    g_force_tile = mode;
+    igemm_big_ablate((mode & 0xF) == 2 ? mode >> 4 : 0);
+    igemm_pp_ablate((mode & 0xF) == 3 ? mode >> 4 : 0);
+}
 
 }  // namespace lavie

@@ -13,7 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(lib, steps):
+    # "path.so@N" runs that library with LAVIE_FORCE_TILE=N (GEMM kernel selection override, see igemm.h)
+    lib, _, mode = lib.partition("@")
     env = dict(os.environ, LAVIE_HIP_LIB=os.path.abspath(lib))
+    if mode:
+        env["LAVIE_FORCE_TILE"] = mode
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1",
                           "--cpu-sample-frames", "0"], env=env, capture_output=True, text=True)
     if out.returncode != 0:
@@ -32,7 +36,7 @@ def main():
         for lib in a.libs:
             d = run(lib, a.steps)
             cls = " ".join(f"{c['name'].split('_')[0]}={c['ms']:.2f}" for c in d["kernel_breakdown"]["classes"] if c["launches"])
-            print(f"round {r} {os.path.basename(lib):28s} {d['value']:.4f} lat/s  {d['ms_per_step'] / 50:.2f} ms/fwd | {cls}", flush=True)
+            print(f"round {r} {os.path.basename(lib):30s} {d['value']:.4f} lat/s  {d['ms_per_step'] / 50:.2f} ms/fwd | {cls}", flush=True)
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ def bench_linear():
     shapes = []
     for M, C in ((81920, 320), (20480, 640), (5120, 1280), (1280, 1280)):
         shapes += [(M, C, C, "out+res"), (M, 3 * C, C, "qkv"), (M, C, 4 * C, "ff2+res"), (M, 8 * C, C, "geglu")]
-    print(f"{'M':>6} {'N':>6} {'K':>5} {'kind':>8} | " + " | ".join(f"mode{m}: us   TF/s   GB/s" for m in (0, 2)))
+    print(f"{'M':>6} {'N':>6} {'K':>5} {'kind':>8} | " + " | ".join(f"mode{m}: us   TF/s   GB/s" for m in (0, 3)))
     for M, N, K, kind in shapes:
         a, w = rnd(M, K), rnd(N, K) / math.sqrt(K)
         bias = torch.randn(N, device=dev)
@@ -44,7 +44,7 @@ def bench_linear():
             w, bias = ops.pack_geglu(w, bias.half())
         out = torch.empty(M, N // 2 if geglu else N, dtype=torch.float16, device=dev)
         row = f"{M:>6} {N:>6} {K:>5} {kind:>8} | "
-        for mode in (0, 2):
+        for mode in (0, 3):
             _lib.load().lavie_debug_force_tile(mode)
             us = timeit(lambda: ops.linear(a, w, bias=None if kind == "qkv" else bias, residual=res, geglu=geglu, out=out))
             fl = 2.0 * M * N * K
@@ -59,7 +59,7 @@ def bench_conv():
              (32, 20, 32, 640, 0, 640), (32, 20, 32, 640, 640, 640), (32, 20, 32, 1280, 640, 640), (32, 20, 32, 320, 0, 640),
              (32, 10, 16, 1280, 0, 1280), (32, 10, 16, 1280, 1280, 1280), (32, 10, 16, 640, 0, 1280),
              (32, 5, 8, 1280, 0, 1280), (32, 5, 8, 1280, 1280, 1280)]
-    print(f"{'NI':>3} {'H':>3} {'W':>3} {'C1':>5} {'C2':>5} {'Cout':>5} | " + " | ".join(f"mode{m}: us   TF/s" for m in (0, 2)))
+    print(f"{'NI':>3} {'H':>3} {'W':>3} {'C1':>5} {'C2':>5} {'Cout':>5} | " + " | ".join(f"mode{m}: us   TF/s" for m in (0, 3)))
     for ni, h, w, c1, c2, cout in cases:
         x1 = rnd(ni * h * w, c1)
         x2 = rnd(ni * h * w, c2) if c2 else None
@@ -67,7 +67,7 @@ def bench_conv():
         wp = ops.pack_conv3x3(wt)
         bias = torch.randn(cout, device=dev)
         row = f"{ni:>3} {h:>3} {w:>3} {c1:>5} {c2:>5} {cout:>5} | "
-        for mode in (0, 2):
+        for mode in (0, 3):
             _lib.load().lavie_debug_force_tile(mode)
             us = timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2))
             fl = 2.0 * ni * h * w * cout * 9 * (c1 + c2)
@@ -135,6 +135,58 @@ def bench_ablate():
             row += f"{name} {us:8.1f} us | "
         print(row)
     _lib.load().lavie_debug_force_tile(0)
+
+
+def bench_ablate_pp():
+    """Which phase paces the 160x320 ping-pong kernel (results are wrong in ablated modes)."""
+    for ni, h, w, c1, c2, cout in ((32, 40, 64, 640, 320, 320), (32, 20, 32, 640, 0, 640), (32, 40, 64, 320, 0, 320)):
+        x1 = rnd(ni * h * w, c1)
+        x2 = rnd(ni * h * w, c2) if c2 else None
+        wp = ops.pack_conv3x3(rnd(cout, c1 + c2, 3, 3) / math.sqrt(9 * (c1 + c2)))
+        bias = torch.randn(cout, device=dev)
+        row = f"pp {ni} {h}x{w} {c1}+{c2}->{cout} | "
+        for rnd_ in range(2):
+            for mode, name in ((0x03, "full"), (0x43, "noSetprio"), (0x13, "noMFMA"), (0x23, "noDMA")):
+                _lib.load().lavie_debug_force_tile(mode)
+                us = timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2), iters=30)
+                row += f"{name} {us:8.1f} us | "
+        print(row)
+    _lib.load().lavie_debug_force_tile(0)
+
+
+def bench_pp_splits():
+    """Split-K sweep of the 160x320 ping-pong kernel on the shapes whose grid does not fill the chip, against the
+    automatic choice of the 128-row kernel."""
+    lib = _lib.load()
+    print("conv: shape | auto(128-row) | pp at S=1,2,3,4,6,8")
+    for ni, h, w, c1, c2, cout in ((32, 10, 16, 1280, 0, 1280), (32, 10, 16, 1280, 1280, 1280), (32, 10, 16, 640, 0, 1280),
+                                   (32, 5, 8, 1280, 0, 1280), (32, 5, 8, 1280, 1280, 1280), (32, 20, 32, 1280, 640, 640),
+                                   (8, 20, 32, 1280, 0, 1280)):
+        x1 = rnd(ni * h * w, c1)
+        x2 = rnd(ni * h * w, c2) if c2 else None
+        wp = ops.pack_conv3x3(rnd(cout, c1 + c2, 3, 3) / math.sqrt(9 * (c1 + c2)))
+        bias = torch.randn(cout, device=dev)
+        lib.lavie_debug_force_tile(0); lib.lavie_debug_force_splits(0)
+        row = f"{ni} {h}x{w} {c1}+{c2}->{cout} | {timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2)):7.1f} | "
+        lib.lavie_debug_force_tile(3)
+        for s_ in (1, 2, 3, 4, 6, 8):
+            lib.lavie_debug_force_splits(s_)
+            row += f"{timeit(lambda: ops.conv3x3(x1, wp, bias, ni, h, w, x2=x2)):7.1f} "
+        print(row)
+    print("linear: M N K | auto(128-row) | pp at S=1,2,3,4,6,8")
+    for M, N, K in ((5120, 1280, 1280), (5120, 1280, 5120), (5120, 3840, 1280), (20480, 640, 640), (20480, 1920, 640),
+                    (1280, 1280, 5120), (1280, 3840, 1280), (81920, 960, 320)):
+        a, w, r = rnd(M, K), rnd(N, K) / math.sqrt(K), rnd(M, N)
+        bias = torch.randn(N, device=dev)
+        out = torch.empty(M, N, dtype=torch.float16, device=dev)
+        lib.lavie_debug_force_tile(0); lib.lavie_debug_force_splits(0)
+        row = f"{M} {N} {K} | {timeit(lambda: ops.linear(a, w, bias=bias, residual=r, out=out)):7.1f} | "
+        lib.lavie_debug_force_tile(3)
+        for s_ in (1, 2, 3, 4, 6, 8):
+            lib.lavie_debug_force_splits(s_)
+            row += f"{timeit(lambda: ops.linear(a, w, bias=bias, residual=r, out=out)):7.1f} "
+        print(row)
+    lib.lavie_debug_force_tile(0); lib.lavie_debug_force_splits(0)
 
 
 def bench_ablate_gemm():
@@ -212,6 +264,12 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "order":
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "splits":
     bench_splits()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pp_splits":
+    bench_pp_splits()
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ablate_pp":
+    bench_ablate_pp()
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ablate":
     bench_ablate()
