@@ -36,7 +36,11 @@ struct AttTile {
 };
 
 // ABL (diagnostic, wrong results): 1 = no softmax VALU (P := S), 2 = no MFMA, 3 = staging + barriers only
-template <int DHP, int QT, int ABL = 0>
+// LSUM: the softmax row sums come out of the P V product itself: column `dh` of every V row in LDS (padding that the
+// staging never writes; it lies inside the last 16-wide output tile whenever dh % 16 != 0) holds 1.0, so output
+// dimension dh accumulates sum_k p[q, k] on the matrix pipe and is rescaled together with O — 16 v_add_f32 per query
+// tile and key tile less on the VALU, which paces this kernel at head dim 40.
+template <int DHP, int QT, int ABL = 0, bool LSUM = false>
 __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention_kernel(const AttnParams p) {
     using T = AttTile<DHP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
         for (int buf = 0; buf < 2; ++buf) {
             *reinterpret_cast<f32x4*>(sK + buf * 2 * T::TILE_BYTES + key * T::STRIDE + c * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(sV + buf * 2 * T::TILE_BYTES + key * T::STRIDE + c * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (LSUM && c == nch) *reinterpret_cast<half_t*>(sV + buf * 2 * T::TILE_BYTES + key * T::STRIDE + c * 16) = (half_t)1.0f;
         }
     }
 
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
                 const float m_new = fmaxf(m_run[qt], mxs);
                 const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);   // first tile: exp2(-inf) = 0
                 m_run[qt] = m_new;
-                l_run[qt] *= alpha;
+                if constexpr (!LSUM) l_run[qt] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < T::DT; ++dt) o[dt][qt] *= alpha;
             }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], sl2, nm));
-                    psum += e[r];
+                    if constexpr (!LSUM) psum += e[r];
                 }
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
                 const half2_t h0 = __builtin_convertvector((f32x2){e[0], e[1]}, half2_t);
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
                 pb[kt >> 1][qt][(kt & 1) * 4 + 2] = h1[0];
                 pb[kt >> 1][qt][(kt & 1) * 4 + 3] = h1[1];
             }
-            l_run[qt] += psum;                                // per-lane partial; reduced over g at the end
+            if constexpr (!LSUM) l_run[qt] += psum;           // per-lane partial; reduced over g at the end
         }
 
         }
@@ -269,8 +274,18 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        if constexpr (LSUM) {
+            // the row sum of query li sits in output dimension dh: tile dh / 16, lane group (dh % 16) / 4, register dh % 4
+            float mine = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < T::DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine = (dt * 16 + g * 4 + r == dh) ? o[dt][qt][r] : mine;
+            l = __shfl(mine, ((dh & 15) >> 2) * 16 + li, 64);
+        } else {
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         const float inv = 1.0f / l;
         const int q = q0 + qt * 16 + li;
         if (q < p.Lq) {
@@ -288,10 +303,10 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
     }
 }
 
-template <int DHP, int QT, int ABL = 0>
+template <int DHP, int QT, int ABL = 0, bool LSUM = false>
 static int launch_att(const AttnParams& p, hipStream_t stream) {
     using T = AttTile<DHP>;
-    auto kern = attention_kernel<DHP, QT, ABL>;
+    auto kern = attention_kernel<DHP, QT, ABL, LSUM>;
     static bool attr_set = false;
     if (!attr_set) {
         LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
@@ -319,8 +334,15 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
     if (g_force_qt == 0x32 && p.dh <= 64) return launch_att<64, 2, 3>(p, stream);
     if (g_force_qt == 1 && p.dh <= 64) return launch_att<64, 1>(p, stream);
     if (g_force_qt == 4 && p.dh <= 64) return launch_att<64, 4>(p, stream);
-    if (p.dh <= 64) return big ? launch_att<64, 2>(p, stream) : launch_att<64, 1>(p, stream);
-    if (p.dh <= 96) return big ? launch_att<96, 2>(p, stream) : launch_att<96, 1>(p, stream);
+    const bool lsum = p.dh % 16 != 0 && g_force_qt != 0x40;     // row sums on the matrix pipe (0x40: A/B switch, VALU sums)
+    if (p.dh <= 64) {
+        if (lsum) return big ? launch_att<64, 2, 0, true>(p, stream) : launch_att<64, 1, 0, true>(p, stream);
+        return big ? launch_att<64, 2>(p, stream) : launch_att<64, 1>(p, stream);
+    }
+    if (p.dh <= 96) {
+        if (lsum) return big ? launch_att<96, 2, 0, true>(p, stream) : launch_att<96, 1, 0, true>(p, stream);
+        return big ? launch_att<96, 2>(p, stream) : launch_att<96, 1>(p, stream);
+    }
     return big ? launch_att<160, 2>(p, stream) : launch_att<160, 1>(p, stream);
 }
 

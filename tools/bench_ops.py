@@ -78,7 +78,7 @@ def bench_conv():
 
 def bench_attn_qt():
     qkv = rnd(32 * 2560, 960)
-    for qt in (1, 2, 4, 0x12, 0x22, 0x32):
+    for qt in (0, 0x40, 0, 0x40, 0x12, 0x22, 0x32):
         _lib.load().lavie_debug_attention_qt(qt)
         us = timeit(lambda: ops.attention(qkv[:, :320], qkv[:, 320:640], qkv[:, 640:], nb=32, lq=2560, lk=2560, heads=8))
         print(f"L0 self-attention QT/ABL={qt:#x}: {us:8.1f} us {4.0 * 32 * 2560 * 2560 * 320 / us / 1e6:6.0f} TF/s")
