@@ -20,8 +20,8 @@ static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 static int g_tap_major = 0;   // diagnostic K-order switch for the op-level conv (pack + launch)
 static float* g_slab = nullptr;
 static size_t g_slab_bytes = 0;
-static int op_slab(IgemmParams& p, int epilogue) {
-    p.splits = igemm_plan_splits(p.M, p.N, p.nk, epilogue);
+static int op_slab(IgemmParams& p, int epilogue, bool gather = false) {
+    p.splits = gather ? igemm_plan_splits_gather(p) : igemm_plan_splits(p.M, p.N, p.nk, epilogue);
     p.slab = nullptr;
     if (p.splits <= 1) return 0;
     const size_t need = (size_t)p.splits * p.M * p.N * sizeof(float);
@@ -93,7 +93,7 @@ int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void
         nk += sg.nchunks;
     }
     p.nseg = ns; p.nk = nk; p.ldw = nk * IGEMM_BK; p.tap_major = g_tap_major;
-    if (int rc = op_slab(p, EPI_LINEAR)) return rc;
+    if (int rc = op_slab(p, EPI_LINEAR, true)) return rc;
     return launch_igemm(p, true, EPI_LINEAR, S(stream));
 }
 

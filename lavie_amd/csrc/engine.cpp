@@ -502,16 +502,6 @@ static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const fl
 static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsrc, const half_t* const* sc, const int* scC,
                    int nsc, const half_t* W, int ldw, const float* bias, const float* bias2, int ldb2, int rows_per_batch,
                    const half_t* R, half_t* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const half_t* zero) {
-    if (c.dry) {
-        const int Ho = ups ? Hi * 2 : (Hi - 1) / stride + 1, Wo = ups ? Wi * 2 : (Wi - 1) / stride + 1;
-        const int s = igemm_plan_splits(NI * Ho * Wo, Cout, ldw / IGEMM_BK, EPI_LINEAR);
-        if (s > 1) {
-            const size_t mark = c.ws->mark();
-            (void)c.ws->alloc((size_t)s * NI * Ho * Wo * Cout * sizeof(float));
-            c.ws->release(mark);
-        }
-        return 0;
-    }
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.W = W; p.ldw = ldw; p.C = y; p.ldc = Cout; p.bias = bias; p.bias2 = bias2; p.ldb2 = ldb2;
@@ -539,13 +529,13 @@ static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsr
     LAVIE_CHECK(nk * IGEMM_BK == ldw, "conv3x3: weight row length %d does not match gathered K %d", ldw, nk * IGEMM_BK);
     p.nseg = ns;
     p.nk = nk;
-    p.splits = igemm_plan_splits(p.M, p.N, nk, EPI_LINEAR);
+    p.splits = igemm_plan_splits_gather(p);        // also picks the kernel: same inputs -> same choice in the dry run
     const size_t mark = c.ws->mark();
     if (p.splits > 1) {
         p.slab = (float*)c.ws->alloc((size_t)p.splits * p.M * p.N * sizeof(float));
-        LAVIE_CHECK(p.slab != nullptr, "workspace exhausted (split-K slab)");
+        if (!c.dry) LAVIE_CHECK(p.slab != nullptr, "workspace exhausted (split-K slab)");
     }
-    const int rc = launch_igemm(p, true, EPI_LINEAR, c.s);
+    const int rc = c.dry ? 0 : launch_igemm(p, true, EPI_LINEAR, c.s);
     c.ws->release(mark);
     return rc;
 }

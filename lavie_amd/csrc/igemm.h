@@ -60,14 +60,21 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
 int launch_igemm_big(const IgemmParams& p, bool gather, hipStream_t stream);
 // 160x320 two-group ping-pong kernel (igemm_pp.hip); EPI_LINEAR only, N %% 320 == 0, the caller runs the split-K reduce.
 int launch_igemm_pp(const IgemmParams& p, bool gather, hipStream_t stream);
+// 320x160 halo-patch 3x3 conv kernel (igemm_patch.hip): stride 1, 9-tap segments only; the caller runs the split-K reduce.
+bool igemm_patch_eligible(const IgemmParams& p);
+int launch_igemm_patch(const IgemmParams& p, hipStream_t stream);
 // Split-K factor the launcher would like for this problem (1 = none); slab size = splits * M * N floats.
 int igemm_plan_splits(int M, int N, int nk, int epilogue);
+// Same for a gathered conv whose geometry and K segments are filled in (M, N, nk, Ho, Wo, stride, ups, seg[], nseg):
+// also considers the halo-patch kernel.
+int igemm_plan_splits_gather(const IgemmParams& p);
 // wave-tile width (16*NT) launch_igemm will pick for a plain, unsplit EPI_LINEAR GEMM: the row-statistics slot width
 int igemm_rowstat_cols(int M, int N, int nk);
 // partials [M, slots, 2] (sum, sum of squares over `row_len` values per row) -> out [M, 2] = (mean, rstd); fixed order
 int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len, float eps, float* out, hipStream_t stream);
 // Low nibble: 0 = automatic kernel / tile choice, 1 = 128-row kernel with the widest tile, 2 = experimental 256x160 kernel,
-// 3 = 160x320 ping-pong kernel whenever N %% 320 == 0, 4 = automatic but never the ping-pong kernel (A/B timing).
+// 3 = 160x320 ping-pong kernel whenever N %% 320 == 0, 4 = automatic but never the ping-pong kernel (A/B timing),
+// 5 = halo-patch conv kernel whenever the conv is eligible, 6 = automatic but never the halo-patch kernel.
 // High nibble: diagnostic ablation build of the forced kernel (results wrong).
 void igemm_force_tile(int mode);
 void igemm_force_splits(int s);   // 0 = automatic

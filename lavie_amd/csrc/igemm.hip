@@ -354,6 +354,28 @@ static int pp_plan(int M, int N, int nk, int epilogue) {
     return 0;
 }
 
+// ---- 320x160 halo-patch conv kernel (igemm_patch.hip): 5-8 % faster than the ping-pong kernel on the convs it accepts
+// (tools/check_patch.py); same grid rule with its own tile: one workgroup per CU, last round at least 85 % full,
+// split-K (over whole slabs) only with at least 45 K-tiles per split.
+static bool patch_fits(int M, int N, int nk, int s) {
+    if (M % 320 != 0 || N % 160 != 0 || nk % 9 != 0 || s < 1 || s > nk / 9) return false;
+    if (s > 1 && nk / s < 45) return false;
+    const double r = (double)(M / 320) * (N / 160) * s / 256.0;
+    return r / ceil(r) >= 0.85;
+}
+static bool patch_allowed() { const int lo = g_force_tile & 0xF; return lo == 0 || lo == 5; }
+
+int igemm_plan_splits_gather(const IgemmParams& p) {
+    if (g_force_splits == 0 && patch_allowed()) {
+        IgemmParams q = p;
+        for (int s = 1; s <= 4; ++s) {
+            q.splits = s;
+            if (patch_fits(p.M, p.N, p.nk, s) && igemm_patch_eligible(q)) return s;
+        }
+    }
+    return igemm_plan_splits(p.M, p.N, p.nk, EPI_LINEAR);
+}
+
 int igemm_plan_splits(int M, int N, int nk, int epilogue) {
     if (epilogue != EPI_LINEAR || N % 64 != 0) return 1;
     if (g_force_splits > 0) return g_force_splits <= nk ? g_force_splits : 1;
@@ -472,9 +494,20 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         if (big) return launch_tile<4, 2, 4, 4, 3, false, EPI_GEGLU>(p, stream);
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
     }
+    // halo-patch conv kernel: forced (mode 5) or whenever its grid rule holds at this split factor
+    if (gather && epilogue == EPI_LINEAR && igemm_patch_eligible(p) &&
+        ((g_force_tile & 0xF) == 5 || ((g_force_tile & 0xF) == 0 && patch_fits(p.M, p.N, p.nk, p.splits)))) {
+        RUN_BIG(launch_igemm_patch(p, stream));
+        if (p.splits > 1) {
+            const long total = (long)p.M * (p.N / 4);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+            LAVIE_HIP(hipGetLastError());
+        }
+        return 0;
+    }
     // 160x320 ping-pong kernel: forced (mode 3) or whenever the planner's rule holds for this problem at its split factor
     const bool use_pp = p.N % 320 == 0 && ((g_force_tile & 0xF) == 3 ||
-                                            ((g_force_tile & 0xF) == 0 && pp_fits(p.M, p.N, p.nk, p.splits)));
+                                            (((g_force_tile & 0xF) == 0 || (g_force_tile & 0xF) == 6) && pp_fits(p.M, p.N, p.nk, p.splits)));
     if (use_pp) {
         RUN_BIG(launch_igemm_pp(p, gather, stream));
         if (p.splits > 1) {

@@ -1,0 +1,300 @@
+// 3x3 convolution (stride 1, pad 1) as a 320x160 implicit-GEMM tile whose activation operand is staged ONCE per
+// 64-channel slab as a halo patch and re-read nine times with shifted LDS addresses (gfx950).
+//
+// Why: the implicit-GEMM kernels of igemm.hip / igemm_pp.hip stage the A tile of every (slab, tap) K-tile separately,
+// so each activation row travels L2 -> LDS nine times and the LDS-DMA issue rate (about one 1-KiB piece per 30 cycles
+// per CU with four issuing waves) paces the loop: 60 pieces per K-tile for the 160x320 tile.  Here a tile is 320
+// CONTIGUOUS output pixels = whole image rows (of one frame, or a whole number of small frames), so the nine taps of a
+// slab read the same (rows + 2 halo rows) x W pixels, just shifted by (dy-1) W + (dx-1) patch rows: the patch is staged
+// once per slab (<= 56 pieces for 9 K-tiles) and only the 160x64 weight tile (20 pieces) is new in every K-tile ->
+// 26 pieces per K-tile for the same 2 x 320 x 160 x 64 flop.  Column wrap-around (x-1 at x = 0, x+1 at x = W-1) is the
+// only case the patch cannot express; those lanes read a 128-B row of zeros instead.
+//
+// Structure = igemm_pp.hip: 8 waves, wave tile 80x80 (4 waves along M, 2 along N), two groups (waves 0-3 / 4-7 = the SIMD
+// partners) half a k-step apart, R phase (fragment reads + LDS-DMA issue) opposite the partner's M phase (25 MFMAs).
+// Group g owns output columns [80 g, 80 g + 80) and alone reads its half of the weight tile.  Per K-tile t:
+//   G0 R(t,0): W rows  0-79  of K-tile t+1 (10 pieces over 4 waves)      G1 R(t,0): W rows 80-159 of K-tile t+1
+//   G0 R(t,1), G1 R(t,1): one piece per wave of the NEXT slab's patch (8 per K-tile, done after 7 of the 9 K-tiles)
+// LDS: 2 patches x 56 KiB + 2 weight stages x 20 KiB + zero row + pixel table = 154 KiB.
+// Restrictions (the launcher falls back otherwise): every K segment has 9 taps (a fused 1x1 shortcut runs as its own
+// GEMM whose result comes back through the residual operand), stride 1, no upsample, M % 320 == 0, W % 8 == 0,
+// 320 % W == 0, tile = part of one frame or whole frames, patch <= 448 rows, split-K only at slab boundaries.
+#include <type_traits>
+
+#include "igemm.h"
+#include "igemm_epilogue.h"
+
+namespace lavie {
+
+namespace pt {
+constexpr int MT = 5, NT = 5;
+constexpr int BM = 320, BN = 160, THREADS = 512;
+constexpr int PATCH_ROWS = 448, PATCH_PIECES = PATCH_ROWS / 8;     // 56
+constexpr int PATCH_BYTES = PATCH_ROWS * 128;                       // 57,344
+constexpr int W_BYTES = BN * 128;                                   // 20,480
+constexpr int W_BASE = 2 * PATCH_BYTES;
+constexpr int ZROW = W_BASE + 2 * W_BYTES;                          // 128 B of zeros (128-B aligned)
+constexpr int PTAB = ZROW + 128;                                    // int[PATCH_ROWS]: source pixel of a patch row or -1
+constexpr int SEGTAB = PTAB + PATCH_ROWS * 4;
+constexpr int LDS_BYTES = SEGTAB + IGEMM_MAX_SEG * 6 * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "does not fit LDS");
+}  // namespace pt
+
+template <int EPI>
+__global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const IgemmParams p) {
+    using namespace pt;
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                    // 0: leading group, 1: trailing group (SIMD partners)
+    const int q = wave & 3;
+    const int wm = q, wn = grp;
+
+    const int n_tiles = p.N / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
+    }
+    const int m0 = (bid / n_tiles) * BM;
+    const int n0 = (bid % n_tiles) * BN;
+    const int split = blockIdx.y;
+    const int nslab = p.nk / 9;
+    const int slab_begin = (int)((long)nslab * split / p.splits);
+    const int slab_end = (int)((long)nslab * (split + 1) / p.splits);
+    const int t_begin = slab_begin * 9, t_end = slab_end * 9;
+
+    const int lr = lane >> 3;
+    const int kofs = ((lane & 7) ^ lr) * 8;         // source K offset (halfs) after the slot swizzle
+    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+
+    // ---- tile geometry: 320 pixels = `rows_seg` image rows of each of `nf` frame segments
+    const int Wd = p.Wo, Hd = p.Ho, HW = Hd * Wd;
+    const int seg_px = HW >= BM ? BM : HW;          // pixels of one frame segment inside the tile
+    const int rows_seg = seg_px / Wd;
+    const int PF = (rows_seg + 2) * Wd;             // patch rows of one segment (with the two halo image rows)
+    const int frame0 = m0 / HW;
+    const int y_first = HW >= BM ? (m0 - frame0 * HW) / Wd : 0;
+
+    int* ptab = reinterpret_cast<int*>(smem + PTAB);
+    int* segtab = reinterpret_cast<int*>(smem + SEGTAB);
+    for (int j = tid; j < PATCH_ROWS; j += THREADS) {
+        const int f = j / PF, jj = j - f * PF;
+        const int jr = jj / Wd, x = jj - jr * Wd;
+        const int yy = y_first - 1 + jr;
+        const bool ok = f * seg_px < BM && (unsigned)yy < (unsigned)Hd;
+        ptab[j] = ok ? ((frame0 + f) * Hd + yy) * Wd + x : -1;
+    }
+    if (tid < 32) reinterpret_cast<float*>(smem + ZROW)[tid] = 0.f;
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < IGEMM_MAX_SEG; ++i) {
+            const unsigned long long a = reinterpret_cast<unsigned long long>(p.seg[i].src);
+            segtab[i * 6 + 0] = (int)(unsigned)a;
+            segtab[i * 6 + 1] = (int)(unsigned)(a >> 32);
+            segtab[i * 6 + 2] = p.seg[i].C;
+            segtab[i * 6 + 3] = p.seg[i].c0;
+            segtab[i * 6 + 4] = p.seg[i].nchunks;
+            segtab[i * 6 + 5] = p.seg[i].ntaps;
+        }
+    }
+    __syncthreads();
+    auto load_seg = [&](int i) -> IgemmSeg {
+        IgemmSeg r;
+        const unsigned lo = (unsigned)sgpr(segtab[i * 6 + 0]), hi = (unsigned)sgpr(segtab[i * 6 + 1]);
+        r.src = reinterpret_cast<const half_t*>(((unsigned long long)hi << 32) | lo);
+        r.C = sgpr(segtab[i * 6 + 2]);
+        r.c0 = sgpr(segtab[i * 6 + 3]);
+        r.nchunks = sgpr(segtab[i * 6 + 4]);
+        r.ntaps = sgpr(segtab[i * 6 + 5]);
+        return r;
+    };
+    const half_t* const zero_page = reinterpret_cast<const half_t*>(
+        ((unsigned long long)(unsigned)sgpr((int)(unsigned)(reinterpret_cast<unsigned long long>(p.zero) >> 32)) << 32) |
+        (unsigned)sgpr((int)(unsigned)reinterpret_cast<unsigned long long>(p.zero)));
+    const int nseg = sgpr(p.nseg);
+
+    // ---- slab cursor: (segment, 64-channel chunk) of the slab whose patch is staged next
+    int seg = 0, chunk = 0;
+    IgemmSeg sg = load_seg(0);
+    {
+        int skip = slab_begin;
+        while (skip >= sg.nchunks && seg + 1 < nseg) {
+            skip -= sg.nchunks;
+            sg = load_seg(++seg);
+        }
+        chunk = skip;
+    }
+    auto advance_slab = [&]() {
+        if (++chunk == sg.nchunks) {
+            chunk = 0;
+            if (seg + 1 < nseg) sg = load_seg(++seg);
+        }
+    };
+    // LDS-DMA of patch piece `i` (8 patch rows) of the cursor's slab into patch buffer `pb`; pix = ptab[i * 8 + lr]
+    auto issue_patch = [&](int i, int pb, int pix) {
+        const unsigned cofs = (unsigned)(sg.c0 + chunk * IGEMM_BK + kofs);
+        const half_t* inside = sg.src + ((unsigned)pix * (unsigned)sg.C + cofs);
+        const half_t* src = pix >= 0 ? inside : zero_page + kofs;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(smem + pb * PATCH_BYTES + i * 1024), 16, 0, 0);
+    };
+
+    // ---- weight pieces of this wave: rows 80 grp + (q + 4 j) * 8, j = 0..2 (j = 2 only for q < 2: 10 pieces per half)
+    const half_t* wptr[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wptr[j] = p.W + (size_t)(n0 + grp * 80 + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
+    const bool w3 = q < 2;
+    auto issue_w = [&](int t, int wst) {
+        char* base = smem + W_BASE + wst * W_BYTES + grp * (80 * 128);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[0] + t * IGEMM_BK), LDS_PTR(base + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[1] + t * IGEMM_BK), LDS_PTR(base + (q + 4) * 1024), 16, 0, 0);
+        if (w3) __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[2] + t * IGEMM_BK), LDS_PTR(base + (q + 8) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment rows of this lane: tile row r = 80 wm + 16 mt + (lane & 15) -> centre patch row and column flags
+    const int frow = lane & 15, fg = lane >> 4;
+    int prow[MT];                                   // patch row | (x == 0) << 16 | (x == W - 1) << 17
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = wm * (MT * 16) + mt * 16 + frow;
+        const int f = r / seg_px, rr = r - f * seg_px;
+        const int x = rr % Wd;
+        prow[mt] = (f * PF + Wd + rr) | ((x == 0) << 16) | ((x == Wd - 1) << 17);
+    }
+    const int w_frag = W_BASE + (wn * (NT * 16) + frow) * 128 + ((fg ^ (frow & 7)) << 4);   // k-step 0; k-step 1 = ^ 64
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    half8_t af[MT], wf[NT];
+    int aaddr[MT];                                  // LDS byte address of this K-tile's A fragments (k-step 0)
+
+    // A-fragment addresses of tap (dy, dx) in patch buffer pb
+    auto tap_addresses = [&](int tap, int pb) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int shift = (dy - 1) * Wd + (dx - 1);
+        const int bad = dx == 0 ? (1 << 16) : (dx == 2 ? (1 << 17) : 0);
+        const int base = pb * PATCH_BYTES;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int u = (prow[mt] & 0xFFFF) + shift;
+            const int a = base + (u << 7) + ((fg ^ (u & 7)) << 4);
+            aaddr[mt] = (prow[mt] & bad) ? ZROW + (fg << 4) : a;
+        }
+    };
+    auto read_frags = [&](int wst, int ks) {
+        const int kx = ks << 6;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const half8_t*>(smem + (aaddr[mt] ^ kx));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            wf[nt] = *reinterpret_cast<const half8_t*>(smem + ((w_frag + wst * W_BYTES + nt * 16 * 128) ^ kx));
+    };
+    auto mfma_block = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+    };
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: patch of the first slab (7 pieces per wave), weight tile of the first K-tile
+#pragma unroll 1
+    for (int j = 0; j < PATCH_PIECES / 8; ++j) {
+        const int i = wave + 8 * j;
+        issue_patch(i, 0, ptab[i * 8 + lr]);
+    }
+    advance_slab();                                 // the cursor now names the slab to prefetch
+    issue_w(t_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    if (grp == 1) bar();                            // the trailing group runs one barrier behind
+
+    int pb = 0, kt = 0;                             // patch buffer of the current slab, tap index inside it
+    int slab = slab_begin;
+    tap_addresses(0, 0);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int wst = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        const bool next_slab = slab + 1 < slab_end;
+        const int piece = kt * 8 + wave;            // patch piece of the next slab this wave stages during this K-tile
+        const bool pissue = next_slab && piece < PATCH_PIECES;
+        // ---- R(t, 0)
+        read_frags(wst, 0);
+        int pix = -1;
+        if (pissue) pix = ptab[piece * 8 + lr];
+        if (more) issue_w(t + 1, wst ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        // ---- M(t, 0)
+        mfma_block();
+        bar();
+        // ---- R(t, 1)
+        read_frags(wst, 1);
+        if (pissue) issue_patch(piece, pb ^ 1, pix);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        // ---- M(t, 1): the address arithmetic of the next tap rides in the issue gaps of this wave's own MFMAs (in an R
+        // phase it would compete with the partner's MFMAs for the SIMD's issue port and cost twice as much)
+        {
+            const bool wrap = kt == 8;
+            tap_addresses(wrap ? 0 : kt + 1, wrap ? pb ^ 1 : pb);
+        }
+        mfma_block();
+        // this wave's weight pieces of K-tile t+1 have landed (the patch piece issued after them may still fly)
+        if (pissue) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(grp == 1 && !more)) bar();
+        if (++kt == 9) {
+            kt = 0;
+            pb ^= 1;
+            ++slab;
+            advance_slab();
+        }
+    }
+
+    igemm_epilogue<MT, NT, EPI>(p, acc, m0 + wm * (MT * 16) + (lane & 15), n0 + wn * (NT * 16) + (lane >> 4) * 4,
+                                n0 + wn * (NT * 16), lane, split);
+}
+
+// Whether the halo-patch kernel can run this conv (geometry only; the caller decides on grid fill and split-K).
+bool igemm_patch_eligible(const IgemmParams& p) {
+    if (p.stride != 1 || p.ups != 0 || p.N % pt::BN != 0 || p.M % pt::BM != 0 || p.nk % 9 != 0) return false;
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.seg[i].ntaps != 9) return false;
+    const int W = p.Wo, HW = p.Ho * p.Wo;
+    if (W % 8 != 0 || pt::BM % W != 0) return false;
+    if (!(HW % pt::BM == 0 || pt::BM % HW == 0)) return false;
+    const int seg_px = HW >= pt::BM ? pt::BM : HW;
+    const int patch_rows = (pt::BM / seg_px) * (seg_px / W + 2) * W;
+    if (patch_rows > pt::PATCH_ROWS || patch_rows >= (1 << 16)) return false;
+    return p.splits >= 1 && p.splits <= p.nk / 9;
+}
+
+// Launches the halo-patch conv kernel (EPI_LINEAR; the caller runs the split-K reduce).
+int launch_igemm_patch(const IgemmParams& p, hipStream_t stream) {
+    using namespace pt;
+    LAVIE_CHECK(igemm_patch_eligible(p), "igemm_patch: conv geometry not supported by the halo-patch kernel");
+    auto kern = igemm_patch_kernel<EPI_LINEAR>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    const int grid = (p.M / BM) * (p.N / BN);
+    hipLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(THREADS), LDS_BYTES, stream, p);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace lavie

@@ -118,6 +118,41 @@ def test_conv3x3_concat_shortcut_temb(ops):
     assert rel_l2(unrows(y.float().cpu(), n, h, w), ref) < TOL_OP
 
 
+@pytest.mark.parametrize("n,c1,c2,cout,h,w,splits", [
+    (5, 64, 0, 160, 8, 8, 0),        # five whole 8x8 frames per 320-pixel tile
+    (10, 128, 0, 320, 8, 8, 2),      # two tiles x two column tiles, split-K over the two slabs
+    (4, 64, 0, 160, 10, 16, 0),      # two whole frames per tile
+    (1, 64, 0, 160, 40, 16, 0),      # tiles of 20 image rows inside one frame (halo rows are real neighbours)
+    (8, 128, 0, 160, 5, 8, 0),       # eight 5x8 frames per tile (the model's deepest level)
+    (2, 64, 64, 160, 20, 16, 0),     # channel concat of two sources, one frame per tile
+    (1, 192, 0, 320, 10, 64, 3),     # W = 64: five image rows per tile, split-K = 3 over three slabs
+])
+def test_conv3x3_halo_patch_kernel(ops, n, c1, c2, cout, h, w, splits):
+    """The 320x160 halo-patch conv kernel (igemm_patch.hip) forced on shapes it accepts, with bias, per-video bias
+    and residual; the same call through the default kernels must agree with it to rounding."""
+    from lavie_amd import _lib
+    lib = _lib.load()
+    g = gen(n * 7 + c1 + cout + h)
+    x1 = q16(torch.randn(n, c1, h, w, generator=g))
+    x2 = q16(torch.randn(n, c2, h, w, generator=g)) if c2 else None
+    wt = q16(torch.randn(cout, c1 + c2, 3, 3, generator=g) / math.sqrt(9 * (c1 + c2)))
+    b = torch.randn(cout, generator=g)
+    b2 = torch.randn(n, cout, generator=g)
+    r = q16(torch.randn(n, cout, h, w, generator=g))
+    xin = torch.cat([x1, x2], 1) if c2 else x1
+    ref = F.conv2d(xin, wt, b, padding=1) + b2[:, :, None, None] + r
+    wp = ops.pack_conv3x3(h16(wt))
+    args = dict(x2=h16(rows(x2)) if c2 else None, bias2=f32(b2), rows_per_batch=h * w, residual=h16(rows(r)))
+    try:
+        lib.lavie_debug_force_tile(5)
+        lib.lavie_debug_force_splits(splits)
+        y = ops.conv3x3(h16(rows(x1)), wp, f32(b), n, h, w, **args)
+    finally:
+        lib.lavie_debug_force_tile(0)
+        lib.lavie_debug_force_splits(0)
+    assert rel_l2(unrows(y.float().cpu(), n, h, w), ref) < TOL_OP
+
+
 def test_conv3x3_residual(ops):
     g = gen(12)
     n, h, w, c = 2, 8, 8, 64
