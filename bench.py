@@ -37,7 +37,8 @@ DDPM_STEPS, GUIDANCE = 50, 7.5
 UNET_TFLOP = 16.219           # algorithmic TFLOP of one CFG forward at this config
 PEAK_MFMA_TFLOPS = 2500.0     # dense fp16, gfx950 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-CLASS_NAMES = ["conv3x3_igemm", "linear_igemm", "attention", "temporal_attention", "group_norm", "layer_norm", "other"]
+CLASS_NAMES = ["conv3x3_igemm", "linear_igemm", "attention", "temporal_attention", "group_norm", "layer_norm", "other",
+               "conv3x3_patch_kernel(subset of conv3x3_igemm)"]
 
 
 def synth_inputs(idx, device):
@@ -56,7 +57,7 @@ def profile_begin(lib, mask, max_events):
 
 def profile_end(lib):
     from lavie_amd import _lib
-    n = 7
+    n = len(CLASS_NAMES)
     launches = (ctypes.c_longlong * n)()
     ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -172,8 +173,8 @@ def main():
     barrier()
 
     use_prof = not args.no_profile
-    if use_prof:   # conv3x3 (dominant) + temporal attention only: ~63 event pairs per forward, negligible
-        profile_begin(lib, 0b1001, 2 * 64 * args.ddpm_steps * args.steps + 1024)
+    if use_prof:   # conv class, its dominant kernel and temporal attention only: ~90 event pairs per forward, negligible
+        profile_begin(lib, 0b10001001, 2 * 96 * args.ddpm_steps * args.steps + 1024)
     t0 = time.perf_counter()
     outs = [one_video(args.warmup + i) for i in range(args.steps)]
     local_lat = torch.cat(outs, dim=0).to(torch.float16)
@@ -208,14 +209,21 @@ def main():
     }
 
     if rank == 0 and timed is not None:
-        conv, temp = timed[0], timed[3]
+        conv_cls, temp, conv = timed[0], timed[3], timed[7]
         if conv["launches"]:
             a = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "igemm_kernel<GATHER> (3x3 conv, implicit GEMM, MFMA 16x16x32 f16)",
+            result["roofline"] = {"kernel": "igemm_patch_kernel<0> (3x3 conv stride 1, halo-patch implicit GEMM, MFMA 16x16x32 f16; "
+                                            "every launch of this kernel in the timed region, all grid sizes)",
                                   "bound": "mfma", "achieved": a, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                   "frac": a / PEAK_MFMA_TFLOPS, "traffic": None, "launches": conv["launches"],
                                   "avg_launch_us": 1e3 * conv["ms"] / conv["launches"],
                                   "flop_per_launch": conv["flops"] / conv["launches"]}
+        if conv_cls["launches"]:    # the whole 3x3-conv class (halo-patch + ping-pong + 128-row kernels, split-K reduces included)
+            a = conv_cls["flops"] / (conv_cls["ms"] * 1e-3) / 1e12
+            result["roofline_conv_class"] = {"kernels": "igemm_patch_kernel, igemm_pp_kernel<true>, igemm_kernel<..., true, ...>, splitk_reduce_kernel",
+                                             "bound": "mfma", "achieved": a, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": a / PEAK_MFMA_TFLOPS, "launches": conv_cls["launches"],
+                                             "avg_launch_us": 1e3 * conv_cls["ms"] / conv_cls["launches"]}
         if temp["launches"]:
             bw = temp["bytes"] / (temp["ms"] * 1e-3) / 1e9
             result["roofline_temporal"] = {"kernel": "temporal_attention_kernel<1>", "bound": "hbm", "achieved": bw,
@@ -237,7 +245,7 @@ def main():
         x2 = torch.cat([lat, lat]).half().contiguous()
         net(x2, 500, encoder_hidden_states=ctx)
         torch.cuda.synchronize()
-        profile_begin(lib, 0x7F, 4096)
+        profile_begin(lib, 0xFF, 4096)
         t1 = time.perf_counter()
         net(x2, 500, encoder_hidden_states=ctx)
         rows = profile_end(lib)

@@ -106,12 +106,16 @@ int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, v
 /* ------------------------------------------------------------------------------------------------
  * Measurement hook: HIP-event timing per kernel class on the launch stream (bench.py's roofline leg).
  * Classes: 0 conv3x3 (implicit GEMM, gathered), 1 linear/1x1/GEGLU GEMM, 2 spatial+text attention core,
- * 3 temporal attention core, 4 GroupNorm, 5 LayerNorm, 6 other.  lavie_profile_end synchronises the
+ * 3 temporal attention core, 4 GroupNorm, 5 LayerNorm, 6 other, 7 the halo-patch conv kernel alone (a subset of
+ * class 0: the events bracket exactly that kernel's launches).  lavie_profile_end synchronises the
  * stream and fills four host arrays of LAVIE_PROFILE_CLASSES entries (launches, milliseconds,
  * algorithmic flops, algorithmic bytes — the per-launch figures are defined in DESIGN.md).
  * ---------------------------------------------------------------------------------------------- */
-#define LAVIE_PROFILE_CLASSES 7
-/* Test/tuning knob for the implicit-GEMM tile choice: 0 automatic, 1 128-row tiles only, 2 256-row tiles. */
+#define LAVIE_PROFILE_CLASSES 8
+/* Test/tuning knob for the implicit-GEMM kernel choice.  Low nibble: 0 automatic, 1 128-row kernel with the widest tile,
+ * 2 experimental 256x160 kernel, 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
+ * kernel, 5 halo-patch conv kernel wherever the conv is eligible, 6 automatic without the halo-patch kernel.
+ * High nibble: diagnostic ablation build of the forced kernel (results wrong). */
 int lavie_debug_force_tile(int mode);
 /* Test/tuning knob: force the split-K factor of the implicit GEMM (0 = automatic). */
 int lavie_debug_force_splits(int s);
@@ -121,6 +125,9 @@ int lavie_debug_conv_tap_major(int on);
 int lavie_debug_attention_qt(int qt);
 /* Tuning knob: LDS bytes one temporal-attention workgroup may stage (smaller = more workgroups per CU). */
 int lavie_debug_temporal_budget(int bytes);
+/* Diagnostic: per-wave phase-segment cycle sums [8 waves][16] of the last halo-patch conv launched in stamp mode
+ * (lavie_debug_force_tile(0x75)); layout in igemm_patch.hip. */
+int lavie_debug_patch_stamps(unsigned long long* out128);
 int lavie_profile_begin(unsigned mask, int max_events);
 int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host);
 

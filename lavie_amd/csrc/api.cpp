@@ -166,6 +166,10 @@ int lavie_debug_force_splits(int s) { igemm_force_splits(s); return 0; }
 int lavie_debug_conv_tap_major(int on) { g_tap_major = on; return 0; }
 int lavie_debug_attention_qt(int qt) { attention_force_qt(qt); return 0; }
 int lavie_debug_temporal_budget(int bytes) { temporal_set_budget(bytes); return 0; }
+int lavie_debug_patch_stamps(unsigned long long* out128) {
+    LAVIE_CHECK(out128, "patch_stamps: null output");
+    return igemm_patch_read_stamps(out128);
+}
 
 int lavie_profile_begin(unsigned mask, int max_events) { return profile_begin(mask, max_events); }
 

@@ -63,6 +63,7 @@ int launch_igemm_pp(const IgemmParams& p, bool gather, hipStream_t stream);
 // 320x160 halo-patch 3x3 conv kernel (igemm_patch.hip): stride 1, 9-tap segments only; the caller runs the split-K reduce.
 bool igemm_patch_eligible(const IgemmParams& p);
 int launch_igemm_patch(const IgemmParams& p, hipStream_t stream);
+int igemm_patch_read_stamps(unsigned long long* out);   // diagnostic stamp build: [8 waves][16] cycle sums of workgroup 0
 // Split-K factor the launcher would like for this problem (1 = none); slab size = splits * M * N floats.
 int igemm_plan_splits(int M, int N, int nk, int epilogue);
 // Same for a gathered conv whose geometry and K segments are filled in (M, N, nk, Ho, Wo, stride, ups, seg[], nseg):

@@ -559,10 +559,12 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
 
 void igemm_big_ablate(int a);
 void igemm_pp_ablate(int a);
+void igemm_patch_set_stamp(int mode);
 void igemm_force_tile(int mode) {
     g_force_tile = mode;
     igemm_big_ablate((mode & 0xF) == 2 ? mode >> 4 : 0);
     igemm_pp_ablate((mode & 0xF) == 3 ? mode >> 4 : 0);
+    igemm_patch_set_stamp(mode == 0x75 ? 1 : mode == 0x85 ? 2 : mode == 0x95 ? 3 : mode == 0xA5 ? 4 : mode == 0xB5 ? 5 : 0);
 }
 
 }  // namespace lavie

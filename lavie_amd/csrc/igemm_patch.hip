@@ -15,7 +15,7 @@
 // Group g owns output columns [80 g, 80 g + 80) and alone reads its half of the weight tile.  Per K-tile t:
 //   G0 R(t,0): W rows  0-79  of K-tile t+1 (10 pieces over 4 waves)      G1 R(t,0): W rows 80-159 of K-tile t+1
 //   G0 R(t,1), G1 R(t,1): one piece per wave of the NEXT slab's patch (8 per K-tile, done after 7 of the 9 K-tiles)
-// LDS: 2 patches x 56 KiB + 2 weight stages x 20 KiB + zero row + pixel table = 154 KiB.
+// LDS: 2 x (patch 56 KiB + zero row) + 2 weight stages x 20 KiB + pixel table + tap table = 159.7 KiB.
 // Restrictions (the launcher falls back otherwise): every K segment has 9 taps (a fused 1x1 shortcut runs as its own
 // GEMM whose result comes back through the residual operand), stride 1, no upsample, M % 320 == 0, W % 8 == 0,
 // 320 % W == 0, tile = part of one frame or whole frames, patch <= 448 rows, split-K only at slab boundaries.
@@ -23,6 +23,7 @@
 
 #include "igemm.h"
 #include "igemm_epilogue.h"
+#include "profile.h"
 
 namespace lavie {
 
@@ -30,17 +31,23 @@ namespace pt {
 constexpr int MT = 5, NT = 5;
 constexpr int BM = 320, BN = 160, THREADS = 512;
 constexpr int PATCH_ROWS = 448, PATCH_PIECES = PATCH_ROWS / 8;     // 56
-constexpr int PATCH_BYTES = PATCH_ROWS * 128;                       // 57,344
+constexpr int PATCH_STRIDE = (PATCH_ROWS + 1) * 128;                // 57,472: 448 patch rows + one row of zeros ("row 448")
 constexpr int W_BYTES = BN * 128;                                   // 20,480
-constexpr int W_BASE = 2 * PATCH_BYTES;
-constexpr int ZROW = W_BASE + 2 * W_BYTES;                          // 128 B of zeros (128-B aligned)
-constexpr int PTAB = ZROW + 128;                                    // int[PATCH_ROWS]: source pixel of a patch row or -1
+constexpr int W_BASE = 2 * PATCH_STRIDE;
+constexpr int PTAB = W_BASE + 2 * W_BYTES;                          // int[PATCH_ROWS]: source pixel of a patch row or -1
 constexpr int SEGTAB = PTAB + PATCH_ROWS * 4;
-constexpr int LDS_BYTES = SEGTAB + IGEMM_MAX_SEG * 6 * 4;
+constexpr int TAPTAB = SEGTAB + IGEMM_MAX_SEG * 6 * 4;              // u16[9][320]: (u << 3) | (u & 7), u = patch row read by
+constexpr int LDS_BYTES = TAPTAB + 9 * BM * 2;                      //   tile row r at that tap (448 = the zero row)
 static_assert(LDS_BYTES <= 160 * 1024, "does not fit LDS");
 }  // namespace pt
 
-template <int EPI>
+// STAMP (diagnostic build, forced with lavie_debug_force_tile(0x75)): s_memtime at every phase boundary; the per-wave sums
+// of workgroup 0 go to g_patch_stamps[wave][segment] (read back with lavie_debug_patch_stamps).  Segments per K-tile:
+// 1 R(t,0) (issue + LDS wait), 2 barrier, 3 M(t,0), 4 barrier, 6 R(t,1), 7 barrier, 8 M(t,1) with the next tap's address
+// arithmetic, 9 LDS-DMA wait, 10 barrier; [11] = K-tiles.  Read the SHARES, never the run time of this build (guide section 7, In-kernel stamps).
+__device__ unsigned long long g_patch_stamps[8 * 16];
+
+template <int EPI, int STAMP = 0>
 __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const IgemmParams p) {
     using namespace pt;
     extern __shared__ __attribute__((aligned(128))) char smem[];
@@ -88,7 +95,19 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         const bool ok = f * seg_px < BM && (unsigned)yy < (unsigned)Hd;
         ptab[j] = ok ? ((frame0 + f) * Hd + yy) * Wd + x : -1;
     }
-    if (tid < 32) reinterpret_cast<float*>(smem + ZROW)[tid] = 0.f;
+    if (tid < 64) reinterpret_cast<float*>(smem + (tid >> 5) * PATCH_STRIDE + PATCH_ROWS * 128)[tid & 31] = 0.f;
+    {   // tap table: which patch row tile row r reads at tap (dy, dx); column wrap-around -> the zero row
+        unsigned short* taptab = reinterpret_cast<unsigned short*>(smem + TAPTAB);
+        for (int idx = tid; idx < 9 * BM; idx += THREADS) {
+            const int tap = idx / BM, r = idx - tap * BM;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int f = r / seg_px, rr = r - f * seg_px;
+            const int x = rr % Wd;
+            const bool bad = (dx == 0 && x == 0) || (dx == 2 && x == Wd - 1);
+            const int u = bad ? PATCH_ROWS : f * PF + Wd + rr + (dy - 1) * Wd + (dx - 1);
+            taptab[idx] = (unsigned short)((u << 3) | (u & 7));
+        }
+    }
     if (tid == 0) {
 #pragma unroll
         for (int i = 0; i < IGEMM_MAX_SEG; ++i) {
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         const unsigned cofs = (unsigned)(sg.c0 + chunk * IGEMM_BK + kofs);
         const half_t* inside = sg.src + ((unsigned)pix * (unsigned)sg.C + cofs);
         const half_t* src = pix >= 0 ? inside : zero_page + kofs;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(smem + pb * PATCH_BYTES + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(smem + pb * PATCH_STRIDE + i * 1024), 16, 0, 0);
     };
 
     // ---- weight pieces of this wave: rows 80 grp + (q + 4 j) * 8, j = 0..2 (j = 2 only for q < 2: 10 pieces per half)
@@ -147,23 +166,21 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
 #pragma unroll
     for (int j = 0; j < 3; ++j) wptr[j] = p.W + (size_t)(n0 + grp * 80 + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
     const bool w3 = q < 2;
-    auto issue_w = [&](int t, int wst) {
+    auto issue_w01 = [&](int t, int wst) {
         char* base = smem + W_BASE + wst * W_BYTES + grp * (80 * 128);
         __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[0] + t * IGEMM_BK), LDS_PTR(base + q * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[1] + t * IGEMM_BK), LDS_PTR(base + (q + 4) * 1024), 16, 0, 0);
+    };
+    auto issue_w2 = [&](int t, int wst) {
+        char* base = smem + W_BASE + wst * W_BYTES + grp * (80 * 128);
         if (w3) __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[2] + t * IGEMM_BK), LDS_PTR(base + (q + 8) * 1024), 16, 0, 0);
     };
 
-    // ---- fragment rows of this lane: tile row r = 80 wm + 16 mt + (lane & 15) -> centre patch row and column flags
+    // ---- fragment rows of this lane: tile row r = 80 wm + 16 mt + (lane & 15); the patch row it reads at a tap comes from
+    // the tap table (two VALU per fragment and K-tile instead of ~10: measured with the stamp build, the address
+    // arithmetic was a quarter of the loop)
     const int frow = lane & 15, fg = lane >> 4;
-    int prow[MT];                                   // patch row | (x == 0) << 16 | (x == W - 1) << 17
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int r = wm * (MT * 16) + mt * 16 + frow;
-        const int f = r / seg_px, rr = r - f * seg_px;
-        const int x = rr % Wd;
-        prow[mt] = (f * PF + Wd + rr) | ((x == 0) << 16) | ((x == Wd - 1) << 17);
-    }
+    const int tap_lane = TAPTAB + (wm * (MT * 16) + frow) * 2;       // + tap * 640 + mt * 32
     const int w_frag = W_BASE + (wn * (NT * 16) + frow) * 128 + ((fg ^ (frow & 7)) << 4);   // k-step 0; k-step 1 = ^ 64
 
     f32x4 acc[NT][MT];
@@ -171,31 +188,34 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    half8_t af[MT], wf[NT];
+    half8_t af0[MT], wf0[NT];
     int aaddr[MT];                                  // LDS byte address of this K-tile's A fragments (k-step 0)
 
-    // A-fragment addresses of tap (dy, dx) in patch buffer pb
-    auto tap_addresses = [&](int tap, int pb) {
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const int shift = (dy - 1) * Wd + (dx - 1);
-        const int bad = dx == 0 ? (1 << 16) : (dx == 2 ? (1 << 17) : 0);
-        const int base = pb * PATCH_BYTES;
+    // A-fragment addresses of a tap in patch buffer pb: tap_read issues the table reads, tap_finish turns them into addresses
+    int tv[MT];
+    auto tap_read = [&](int tap) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int u = (prow[mt] & 0xFFFF) + shift;
-            const int a = base + (u << 7) + ((fg ^ (u & 7)) << 4);
-            aaddr[mt] = (prow[mt] & bad) ? ZROW + (fg << 4) : a;
+        for (int mt = 0; mt < MT; ++mt)
+            tv[mt] = *reinterpret_cast<const unsigned short*>(smem + tap_lane + tap * (BM * 2) + mt * 32);
+    };
+    auto tap_finish = [&](int pb) {
+        const int base = pb * PATCH_STRIDE;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aaddr[mt] = ((tv[mt] ^ fg) << 4) + base;
+    };
+    auto read_frags = [&](int wst, int ks, half8_t (&af)[MT], half8_t (&wf)[NT]) {
+        const int kx = ks << 6;
+        if (STAMP != 5) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const half8_t*>(smem + (aaddr[mt] ^ kx));
+        }
+        if (STAMP != 4) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const half8_t*>(smem + ((w_frag + wst * W_BYTES + nt * 16 * 128) ^ kx));
         }
     };
-    auto read_frags = [&](int wst, int ks) {
-        const int kx = ks << 6;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const half8_t*>(smem + (aaddr[mt] ^ kx));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            wf[nt] = *reinterpret_cast<const half8_t*>(smem + ((w_frag + wst * W_BYTES + nt * 16 * 128) ^ kx));
-    };
-    auto mfma_block = [&]() {
+    auto mfma_block = [&](half8_t (&af)[MT], half8_t (&wf)[NT]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -215,46 +235,71 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         issue_patch(i, 0, ptab[i * 8 + lr]);
     }
     advance_slab();                                 // the cursor now names the slab to prefetch
-    issue_w(t_begin, 0);
+    issue_w01(t_begin, 0);
+    issue_w2(t_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar();
     if (grp == 1) bar();                            // the trailing group runs one barrier behind
 
+    unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int seg_id) {
+        if constexpr (STAMP != 0) {
+            unsigned long long tnow;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (seg_id >= 0) st_sum[seg_id] += tnow - st_prev;
+            st_prev = tnow;
+        }
+    };
     int pb = 0, kt = 0;                             // patch buffer of the current slab, tap index inside it
     int slab = slab_begin;
-    tap_addresses(0, 0);
+    // (Measured and rejected: reading a phase's fragments during the previous M phase of the same wave.  The reads then
+    // sit beside the wave's own MFMAs and the M phase grows by more than the R phase shrinks: LDS returns and MFMA
+    // operand traffic share the SIMD's register ports.)
+    tap_read(0);
+    tap_finish(0);
+    stamp(-1);
     for (int t = t_begin; t < t_end; ++t) {
         const int wst = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
         const bool next_slab = slab + 1 < slab_end;
         const int piece = kt * 8 + wave;            // patch piece of the next slab this wave stages during this K-tile
         const bool pissue = next_slab && piece < PATCH_PIECES;
-        // ---- R(t, 0)
-        read_frags(wst, 0);
+        // ---- R(t, 0): fragments, two weight pieces of K-tile t+1, the pixel of this K-tile's patch piece
+        read_frags(wst, 0, af0, wf0);
         int pix = -1;
         if (pissue) pix = ptab[piece * 8 + lr];
-        if (more) issue_w(t + 1, wst ^ 1);
+        if (more && STAMP != 2) issue_w01(t + 1, wst ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(1);
         bar();
+        stamp(2);
         // ---- M(t, 0)
-        mfma_block();
+        mfma_block(af0, wf0);
+        stamp(3);
         bar();
-        // ---- R(t, 1)
-        read_frags(wst, 1);
-        if (pissue) issue_patch(piece, pb ^ 1, pix);
+        stamp(4);
+        // ---- R(t, 1): fragments, the third weight piece, one patch piece of the next slab, next tap's table entries
+        read_frags(wst, 1, af0, wf0);
+        const bool wrap = kt == 8;
+        tap_read(wrap ? 0 : kt + 1);
+        if (more && STAMP != 2) issue_w2(t + 1, wst ^ 1);
+        if (pissue && STAMP != 3) issue_patch(piece, pb ^ 1, pix);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tap_finish(wrap ? pb ^ 1 : pb);
+        stamp(6);
         bar();
-        // ---- M(t, 1): the address arithmetic of the next tap rides in the issue gaps of this wave's own MFMAs (in an R
-        // phase it would compete with the partner's MFMAs for the SIMD's issue port and cost twice as much)
-        {
-            const bool wrap = kt == 8;
-            tap_addresses(wrap ? 0 : kt + 1, wrap ? pb ^ 1 : pb);
-        }
-        mfma_block();
+        stamp(7);
+        // ---- M(t, 1)
+        mfma_block(af0, wf0);
+        stamp(8);
         // this wave's weight pieces of K-tile t+1 have landed (the patch piece issued after them may still fly)
         if (pissue) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(9);
         if (!(grp == 1 && !more)) bar();
+        stamp(10);
         if (++kt == 9) {
             kt = 0;
             pb ^= 1;
@@ -263,8 +308,22 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         }
     }
 
+    if constexpr (STAMP != 0) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 11; ++i) g_patch_stamps[wave * 16 + i] = st_sum[i];
+            g_patch_stamps[wave * 16 + 11] = (unsigned long long)(t_end - t_begin);
+        }
+    }
     igemm_epilogue<MT, NT, EPI>(p, acc, m0 + wm * (MT * 16) + (lane & 15), n0 + wn * (NT * 16) + (lane >> 4) * 4,
                                 n0 + wn * (NT * 16), lane, split);
+}
+
+static int g_patch_stamp = 0;      // 0 off, 1 stamps, 2 stamps without the weight LDS-DMA (wrong results), 3 stamps without the patch LDS-DMA
+void igemm_patch_set_stamp(int mode) { g_patch_stamp = mode; }
+int igemm_patch_read_stamps(unsigned long long* out) {
+    LAVIE_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_patch_stamps), sizeof(unsigned long long) * 8 * 16));
+    return 0;
 }
 
 // Whether the halo-patch kernel can run this conv (geometry only; the caller decides on grid fill and split-K).
@@ -285,13 +344,22 @@ bool igemm_patch_eligible(const IgemmParams& p) {
 int launch_igemm_patch(const IgemmParams& p, hipStream_t stream) {
     using namespace pt;
     LAVIE_CHECK(igemm_patch_eligible(p), "igemm_patch: conv geometry not supported by the halo-patch kernel");
-    auto kern = igemm_patch_kernel<EPI_LINEAR>;
+    auto kern = g_patch_stamp == 1 ? igemm_patch_kernel<EPI_LINEAR, 1> : g_patch_stamp == 2 ? igemm_patch_kernel<EPI_LINEAR, 2>
+                : g_patch_stamp == 3 ? igemm_patch_kernel<EPI_LINEAR, 3> : g_patch_stamp == 4 ? igemm_patch_kernel<EPI_LINEAR, 4>
+                : g_patch_stamp == 5 ? igemm_patch_kernel<EPI_LINEAR, 5> : igemm_patch_kernel<EPI_LINEAR, 0>;
     static bool attr_set = false;
     if (!attr_set) {
-        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     const int grid = (p.M / BM) * (p.N / BN);
+    const double K = (double)p.nk * IGEMM_BK;
+    ProfileScope prof(KC_CONV_PATCH, stream, 2.0 * p.M * p.N * K, 2.0 * ((double)p.M * K / 9.0 + (double)p.N * K + (double)p.M * p.N));
     hipLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(THREADS), LDS_BYTES, stream, p);
     LAVIE_HIP(hipGetLastError());
     return 0;

@@ -13,7 +13,8 @@ enum KernelClass {
     KC_GROUPNORM = 4,
     KC_LAYERNORM = 5,
     KC_OTHER = 6,
-    KC_COUNT = 7
+    KC_CONV_PATCH = 7,  // igemm_patch_kernel alone (a subset of KC_CONV3X3: the scope brackets exactly that kernel launch)
+    KC_COUNT = 8
 };
 
 struct ProfileScope {

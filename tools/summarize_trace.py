@@ -36,6 +36,17 @@ def main():
                 a[3] = max(a[3], dur)
                 total += dur
     print(f"# kernel trace summary ({len(files)} file(s)); total device time {total / 1e3:.2f} ms\n")
+    # per-kernel totals over all grid sizes (what bench.py's roofline.avg_launch_us is checked against)
+    per = defaultdict(lambda: [0, 0.0])
+    for key, a in agg.items():
+        k = re.sub(r"<.*$", "", key[0]) if not key[0].startswith("igemm") else key[0]
+        per[k][0] += a[0]
+        per[k][1] += a[1]
+    print("| kernel (all grid sizes) | launches | total ms | avg us |")
+    print("|---|---|---|---|")
+    for k, a in sorted(per.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"| `{k}` | {a[0]} | {a[1] / 1e3:.3f} | {a[1] / a[0]:.1f} |")
+    print()
     print("| kernel | grid (threads) | wg | launches | total ms | % | avg us | min us | max us |")
     print("|---|---|---|---|---|---|---|---|---|")
     for key, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
