@@ -27,41 +27,74 @@ int launch_timestep_sinusoid(const float* t, float* out, int B, int dim, hipStre
     return 0;
 }
 
-// Batched GEMV for the [B <= 8, K] time-embedding vectors: one wave per output feature.
+// Batched GEMV for the [B <= 8, K] time-embedding vectors.
 // Serves TimestepEmbedding (unet.py:434) and all ResnetBlock3D.time_emb_proj at once (resnet.py:186).
+// HBM-bound on the weight matrix (19840 x 1280 halfs = 50 MB for the stacked projections): the activated input vectors
+// are staged once per workgroup in LDS (fp32), each wave then streams GEMV_ROWS weight rows at a time with 16-byte loads
+// (four independent loads in flight per lane) and reduces across the wave.
 constexpr int GEMV_MAXB = 8;
+constexpr int GEMV_ROWS = 4;           // weight rows per wave and pass
+constexpr int GEMV_PASSES = 2;         // passes per wave: a workgroup covers 4 waves x 4 rows x 2 = 32 output features
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ in, const half_t* __restrict__ W,
                                                   const float* __restrict__ bias, float* __restrict__ out, int B, int N,
                                                   int K, int act_in, int act_out) {
+    extern __shared__ __attribute__((aligned(16))) char gemv_smem[];
+    float* sx = reinterpret_cast<float*>(gemv_smem);            // [B][K]
+    for (int i = threadIdx.x; i < B * K; i += 256) {
+        float x = in[i];
+        if (act_in) x = silu_f(x);
+        sx[i] = x;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    float acc[GEMV_MAXB];
+    const int wave = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int pass = 0; pass < GEMV_PASSES; ++pass) {
+        const int n0 = (blockIdx.x * GEMV_PASSES + pass) * (4 * GEMV_ROWS) + wave * GEMV_ROWS;
+        if (n0 >= N) return;
+        float acc[GEMV_ROWS][GEMV_MAXB];
 #pragma unroll
-    for (int b = 0; b < GEMV_MAXB; ++b) acc[b] = 0.f;
-    const half_t* wr = W + (size_t)n * K;
-    for (int k = lane * 8; k < K; k += 64 * 8) {
-        const half8_t w = *reinterpret_cast<const half8_t*>(wr + k);
+        for (int r = 0; r < GEMV_ROWS; ++r)
 #pragma unroll
-        for (int b = 0; b < GEMV_MAXB; ++b) {
-            if (b < B) {
+            for (int b = 0; b < GEMV_MAXB; ++b) acc[r][b] = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            half8_t w[GEMV_ROWS];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float x = in[(size_t)b * K + k + j];
-                    if (act_in) x = silu_f(x);
-                    acc[b] += x * (float)w[j];
+            for (int r = 0; r < GEMV_ROWS; ++r) {
+                const int n = n0 + r < N ? n0 + r : N - 1;
+                w[r] = *reinterpret_cast<const half8_t*>(W + (size_t)n * K + k);
+            }
+#pragma unroll
+            for (int b = 0; b < GEMV_MAXB; ++b) {
+                if (b < B) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(sx + b * K + k);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(sx + b * K + k + 4);
+#pragma unroll
+                    for (int r = 0; r < GEMV_ROWS; ++r) {
+                        // explicit fma chain in a fixed order: every batch entry must round identically (identical CFG
+                        // halves give bit-identical outputs; a contracted sum-of-products expression did not guarantee it)
+                        float a = acc[r][b];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a = __builtin_fmaf(x0[j], (float)w[r][j], a);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a = __builtin_fmaf(x1[j], (float)w[r][4 + j], a);
+                        acc[r][b] = a;
+                    }
                 }
             }
         }
-    }
 #pragma unroll
-    for (int b = 0; b < GEMV_MAXB; ++b) {
-        if (b < B) {
-            float v = wave_sum(acc[b]);
-            if (lane == 0) {
-                v += bias ? bias[n] : 0.f;
-                if (act_out) v = silu_f(v);
-                out[(size_t)b * N + n] = v;
+        for (int r = 0; r < GEMV_ROWS; ++r) {
+#pragma unroll
+            for (int b = 0; b < GEMV_MAXB; ++b) {
+                if (b < B) {
+                    float v = wave_sum(acc[r][b]);
+                    if (lane == 0 && n0 + r < N) {
+                        v += bias ? bias[n0 + r] : 0.f;
+                        if (act_out) v = silu_f(v);
+                        out[(size_t)b * N + n0 + r] = v;
+                    }
+                }
             }
         }
     }
@@ -70,7 +103,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ in,
 int launch_gemv(const float* in, const half_t* W, const float* bias, float* out, int B, int N, int K, int act_in,
                 int act_out, hipStream_t stream) {
     LAVIE_CHECK(B >= 1 && B <= GEMV_MAXB && K % 8 == 0, "gemv: unsupported B=%d K=%d", B, K);
-    hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, stream, in, W, bias, out, B, N, K, act_in, act_out);
+    const size_t lds = (size_t)B * K * sizeof(float);
+    LAVIE_CHECK(lds <= 64 * 1024, "gemv: B * K = %d does not fit the LDS staging buffer", B * K);
+    hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(N, 4 * GEMV_ROWS * GEMV_PASSES)), dim3(256), lds, stream, in, W, bias, out, B, N, K,
+                       act_in, act_out);
     LAVIE_HIP(hipGetLastError());
     return 0;
 }
@@ -82,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* __restrict__
                                                      const float* __restrict__ bias, half_t* __restrict__ y, int B,
                                                      int Cin, int F, int H, int W, int Cout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* sw = reinterpret_cast<half_t*>(smem);
+    half_t* sw = reinterpret_cast<half_t*>(smem);               // [(tap * Cin + ci) / 2][Cout][2]: K pairs interleaved
     const int kk = 9 * Cin;
     for (int i = threadIdx.x * 8; i < kk * Cout; i += 256 * 8)
         *reinterpret_cast<half8_t*>(sw + i) = *reinterpret_cast<const half8_t*>(wp + i);
@@ -100,17 +136,24 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* __restrict__
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = bias[g * 8 + j];
+    // the kernel is VALU-issue bound (K = 36 per output): v_dot2_f32_f16 takes two input channels per slot
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = yh + ky - 1;
         if ((unsigned)iy >= (unsigned)H) continue;
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = xw + kx - 1;
             if ((unsigned)ix >= (unsigned)W) continue;
-            for (int ci = 0; ci < Cin; ++ci) {
-                const float v = (float)x[((((size_t)b * Cin + ci) * F + f) * H + iy) * W + ix];
-                const half8_t w = *reinterpret_cast<const half8_t*>(sw + ((ky * 3 + kx) * Cin + ci) * Cout + g * 8);
+            for (int ci = 0; ci < Cin; ci += 2) {
+                const half2_t v = {x[((((size_t)b * Cin + ci) * F + f) * H + iy) * W + ix],
+                                   x[((((size_t)b * Cin + ci + 1) * F + f) * H + iy) * W + ix]};
+                const half_t* wr = sw + ((size_t)(((ky * 3 + kx) * Cin + ci) >> 1) * Cout + g * 8) * 2;
+                const half8_t w0 = *reinterpret_cast<const half8_t*>(wr);
+                const half8_t w1 = *reinterpret_cast<const half8_t*>(wr + 8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += v * (float)w[j];
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] = __builtin_amdgcn_fdot2(v, (half2_t){w0[2 * j], w0[2 * j + 1]}, acc[j], false);
+                    acc[j + 4] = __builtin_amdgcn_fdot2(v, (half2_t){w1[2 * j], w1[2 * j + 1]}, acc[j + 4], false);
+                }
             }
         }
     }
@@ -122,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* __restrict__
 
 int launch_conv_in(const half_t* x, const half_t* wp, const float* bias, half_t* y, int B, int Cin, int F, int H, int W,
                    int Cout, hipStream_t stream) {
-    LAVIE_CHECK(Cout % 8 == 0 && (9 * Cin * Cout) % 8 == 0, "conv_in: Cout must be a multiple of 8");
+    LAVIE_CHECK(Cout % 8 == 0 && Cin % 2 == 0, "conv_in: Cout must be a multiple of 8 and Cin even (Cout=%d Cin=%d)", Cout, Cin);
     const size_t lds = (size_t)9 * Cin * Cout * sizeof(half_t);
     LAVIE_CHECK(lds <= 64 * 1024, "conv_in: weights do not fit LDS (%zu B)", lds);
     const long total = (long)B * F * H * W * (Cout / 8);
@@ -161,12 +204,14 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
         const int iy = yh + tap / 3 - 1, ix = xw + tap % 3 - 1;
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
         const half8_t v = *reinterpret_cast<const half8_t*>(x + ((img * H + iy) * W + ix) * Cin + vec * 8);
+        // v_dot2_f32_f16: two multiply-adds per VALU slot, fp32 accumulation (the kernel is VALU-issue bound, not HBM bound)
 #pragma unroll
         for (int c = 0; c < CONV_OUT_MAXC; ++c) {
             if (c < Cout) {
                 const half8_t w = *reinterpret_cast<const half8_t*>(sw + (size_t)c * kk + tap * Cin + vec * 8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[c] += (float)v[j] * (float)w[j];
+                for (int j = 0; j < 8; j += 2)
+                    acc[c] = __builtin_amdgcn_fdot2((half2_t){v[j], v[j + 1]}, (half2_t){w[j], w[j + 1]}, acc[c], false);
             }
         }
     }
@@ -408,12 +453,13 @@ int launch_pack_geglu_vec(const float* in, float* out, int N, hipStream_t stream
     return 0;
 }
 
-// conv_in weights [Cout][Cin][3][3] -> [(ky*3+kx)*Cin + ci][Cout]
+// conv_in weights [Cout][Cin][3][3] -> [k / 2][Cout][k & 1] with k = (ky*3+kx)*Cin + ci (K pairs interleaved for v_dot2)
 __global__ void pack_conv_in_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Cout * Cin * 9) return;
     const int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
-    out[(size_t)(tap * Cin + ci) * Cout + co] = w[i];
+    const int k = tap * Cin + ci;
+    out[((size_t)(k >> 1) * Cout + co) * 2 + (k & 1)] = w[i];
 }
 
 int launch_pack_conv_in(const half_t* w, half_t* out, int Cout, int Cin, hipStream_t stream) {
