@@ -60,6 +60,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
 int launch_igemm_big(const IgemmParams& p, bool gather, hipStream_t stream);
 // 160x320 two-group ping-pong kernel (igemm_pp.hip); EPI_LINEAR only, N %% 320 == 0, the caller runs the split-K reduce.
 int launch_igemm_pp(const IgemmParams& p, bool gather, hipStream_t stream);
+int launch_igemm_pp_geglu(const IgemmParams& p, hipStream_t stream);   // 160x256 variant, GEGLU epilogue, N %% 256 == 0
 // 320x160 halo-patch 3x3 conv kernel (igemm_patch.hip): stride 1, 9-tap segments only; the caller runs the split-K reduce.
 bool igemm_patch_eligible(const IgemmParams& p);
 int launch_igemm_patch(const IgemmParams& p, hipStream_t stream);

@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
 // Split-K factor for an under-filled grid.  The 128-row tiles run 2 workgroups per CU (512 slots); a grid of
 // `blocks` tiles takes ceil(blocks*S/512) rounds of (nk/S + fixed) K-steps plus a reduce pass over S slabs.
 static int g_force_tile = 0;   // see igemm_force_tile() in igemm.h
+static int g_geglu_pp_min_nk = 16;   // measured: the GEGLU epilogue (no second workgroup to hide it) loses below ~16 K-tiles
 static bool g_big_auto = false;    // flipped on once the big kernel wins on the shapes above
 static int g_force_splits = 0;
 void igemm_force_splits(int s) { g_force_splits = s; }
@@ -492,6 +493,12 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         LAVIE_CHECK(!p.R && !p.bias2, "igemm: GEGLU epilogue takes no residual / per-batch bias");
         LAVIE_CHECK(!gather, "igemm: GEGLU epilogue is only built for plain A rows");
         if (big) return launch_tile<4, 2, 4, 4, 3, false, EPI_GEGLU>(p, stream);
+        {   // 160x256 ping-pong variant: same grid rule as the 160x320 kernel, from g_geglu_pp_min_nk K-tiles on
+            const int lo = g_force_tile & 0xF;
+            const double r = (double)cdiv(p.M, 160) * (p.N / 256) / 256.0;
+            if (p.N % 256 == 0 && (lo == 3 || ((lo == 0 || lo == 6) && p.nk >= g_geglu_pp_min_nk && r / ceil(r) >= 0.85)))
+                return launch_igemm_pp_geglu(p, stream);
+        }
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
     }
     // halo-patch conv kernel: forced (mode 5) or whenever its grid rule holds at this split factor

@@ -30,21 +30,33 @@
 namespace lavie {
 
 namespace pp {
-constexpr int MT = 5, NT = 5;
-constexpr int BM = 160, BN = 320, THREADS = 512;
-constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;   // one stage of each operand: 20,480 / 40,960
+constexpr int MT = 5;
+constexpr int BM = 160, THREADS = 512;
+constexpr int A_BYTES = BM * 128;                       // one A stage: 20,480
 constexpr int A_STAGES = 3, W_STAGES = 2;
 constexpr int W_BASE = A_STAGES * A_BYTES;              // A stages first, then W stages
-constexpr int LDS_BYTES = W_BASE + W_STAGES * W_BYTES;  // 143,360
 constexpr int TAB_BYTES = BM * 9 * 4 + IGEMM_MAX_SEG * 6 * 4;
-static_assert(LDS_BYTES + TAB_BYTES <= 160 * 1024, "does not fit LDS");
+// NT = 16-wide column tiles per wave: 5 -> 160x320 block tile (every EPI_LINEAR GEMM with N % 320 == 0),
+// 4 -> 160x256 (GEGLU: value / gate tile pairs need an even NT; N = 8 C is a multiple of 256)
+template <int NT>
+struct Geo {
+    static constexpr int BN = 4 * NT * 16;
+    static constexpr int HALF_ROWS = 2 * NT * 16;       // W rows read by one group
+    static constexpr int HALF_PIECES = HALF_ROWS / 8;   // 20 or 16: group 0 stages 16 of each half, group 1 the rest
+    static constexpr int W_BYTES = BN * 128;
+    static constexpr int LDS_BYTES = W_BASE + W_STAGES * W_BYTES;
+    static_assert(LDS_BYTES + TAB_BYTES <= 160 * 1024, "does not fit LDS");
+};
 }  // namespace pp
 
 // ABL (diagnostic builds, wrong results): 1 = no MFMA, 2 = no LDS-DMA after the prologue, 3 = MFMAs and barriers only;
 // 4 = s_setprio 1 around the MFMA blocks (results correct; measured 0-10 % slower: it starves the partner's LDS-DMA issue)
-template <bool GATHER, int EPI, int ABL = 0>
+template <bool GATHER, int EPI, int ABL = 0, int NT = 5>
 __global__ __launch_bounds__(pp::THREADS, 2) void igemm_pp_kernel(const IgemmParams p) {
     using namespace pp;
+    using G = Geo<NT>;
+    constexpr int BN = G::BN, W_BYTES = G::W_BYTES, LDS_BYTES = G::LDS_BYTES, HALF_ROWS = G::HALF_ROWS;
+    constexpr bool G1_W = G::HALF_PIECES > 16;            // group 1 stages W pieces 16.. of each half (NT = 5 only)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -136,13 +148,14 @@ __global__ __launch_bounds__(pp::THREADS, 2) void igemm_pp_kernel(const IgemmPar
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             wp[j] = p.W + (size_t)(n0 + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
-            wp2[j] = p.W + (size_t)(n0 + 160 + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
+            wp2[j] = p.W + (size_t)(n0 + HALF_ROWS + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
         }
     } else {
+        const int r16 = G1_W ? (16 + q) * 8 : 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            wp[j] = p.W + (size_t)(n0 + (16 + q) * 8 + lr) * p.ldw + kofs;
-            wp2[j] = p.W + (size_t)(n0 + 160 + (16 + q) * 8 + lr) * p.ldw + kofs;
+            wp[j] = p.W + (size_t)(n0 + r16 + lr) * p.ldw + kofs;
+            wp2[j] = p.W + (size_t)(n0 + HALF_ROWS + r16 + lr) * p.ldw + kofs;
         }
     }
 
@@ -200,16 +213,16 @@ __global__ __launch_bounds__(pp::THREADS, 2) void igemm_pp_kernel(const IgemmPar
     };
     auto issue_w_g0 = [&](int t, int wst, int half) {   // group 0: four pieces of W_lo (half 0) or W_hi (half 1)
         if ((ABL == 2 || ABL == 3) && abl_skip) return;
-        char* base = smem + W_BASE + wst * W_BYTES + half * (160 * 128);
+        char* base = smem + W_BASE + wst * W_BYTES + half * (HALF_ROWS * 128);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_global_load_lds(GLB_PTR((half ? wp2[j] : wp[j]) + t * IGEMM_BK), LDS_PTR(base + (q + 4 * j) * 1024), 16, 0, 0);
     };
     auto issue_w_g1 = [&](int t, int wst) {             // group 1: piece 16 + q of W_lo and of W_hi
-        if ((ABL == 2 || ABL == 3) && abl_skip) return;
+        if (((ABL == 2 || ABL == 3) && abl_skip) || !G1_W) return;
         char* base = smem + W_BASE + wst * W_BYTES;
         __builtin_amdgcn_global_load_lds(GLB_PTR(wp[0] + t * IGEMM_BK), LDS_PTR(base + (16 + q) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(wp2[0] + t * IGEMM_BK), LDS_PTR(base + 160 * 128 + (16 + q) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(wp2[0] + t * IGEMM_BK), LDS_PTR(base + HALF_ROWS * 128 + (16 + q) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[NT][MT];
@@ -329,11 +342,12 @@ __global__ __launch_bounds__(pp::THREADS, 2) void igemm_pp_kernel(const IgemmPar
                                 n0 + wn * (NT * 16), lane, split);
 }
 
-template <bool GATHER, int ABL = 0>
+template <bool GATHER, int ABL = 0, int EPI = EPI_LINEAR, int NT = 5>
 static int launch_pp_t(const IgemmParams& p, hipStream_t stream) {
     using namespace pp;
-    constexpr int lds = LDS_BYTES + (GATHER ? TAB_BYTES : 0);
-    auto kern = igemm_pp_kernel<GATHER, EPI_LINEAR, ABL>;
+    constexpr int BN = Geo<NT>::BN;
+    constexpr int lds = Geo<NT>::LDS_BYTES + (GATHER ? TAB_BYTES : 0);
+    auto kern = igemm_pp_kernel<GATHER, EPI, ABL, NT>;
     static bool attr_set = false;
     if (!attr_set) {
         LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -348,9 +362,15 @@ static int launch_pp_t(const IgemmParams& p, hipStream_t stream) {
 static int g_pp_abl = 0;
 void igemm_pp_ablate(int a) { g_pp_abl = a; }
 
+// 160x256 variant with the GEGLU epilogue (plain A rows, no split-K).  N % 256 == 0.
+int launch_igemm_pp_geglu(const IgemmParams& p, hipStream_t stream) {
+    LAVIE_CHECK(p.N % 256 == 0 && p.splits == 1, "igemm_pp_geglu: N=%d must be a multiple of 256, no split-K", p.N);
+    return launch_pp_t<false, 0, EPI_GEGLU, 4>(p, stream);
+}
+
 // Launches the 160x320 ping-pong kernel (EPI_LINEAR only; the caller runs the split-K reduce).  N % 320 == 0.
 int launch_igemm_pp(const IgemmParams& p, bool gather, hipStream_t stream) {
-    LAVIE_CHECK(p.N % pp::BN == 0, "igemm_pp: N=%d is not a multiple of %d", p.N, pp::BN);
+    LAVIE_CHECK(p.N % 320 == 0, "igemm_pp: N=%d is not a multiple of 320", p.N);
     if (gather && g_pp_abl == 1) return launch_pp_t<true, 1>(p, stream);
     if (gather && g_pp_abl == 2) return launch_pp_t<true, 2>(p, stream);
     if (gather && g_pp_abl == 3) return launch_pp_t<true, 3>(p, stream);
