@@ -61,18 +61,36 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
     // ---- stage q | k | v : piece = (array a, pixel pp, frame f, 16-B chunk c)
     const int cpr = RL >> 3;                        // chunks per row
     const int total = 3 * PT * FP * cpr;
-    for (int i = tid; i < total; i += 256) {
-        const int c = i % cpr;
-        int r = i / cpr;
-        const int pp = r % PT; r /= PT;             // pixel fastest: consecutive rows in HBM
-        const int f = r % FP;
-        const int a = r / FP;
-        half8_t v = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        if (f < F && pp < npix) {
-            const size_t tok = ((size_t)b * F + f) * p.D + p0 + pp;
-            v = *reinterpret_cast<const half8_t*>(p.qkv + tok * p.ld + a * C + col0 + c * 8);
+    // Eight pieces per thread and pass: all eight 16-B loads are issued before the first LDS store, so a pass costs one
+    // memory latency instead of eight (the kernel has no compute to hide loads under; a one-piece loop serialised them).
+    constexpr int SU = 8;
+    for (int i0 = tid; i0 < total; i0 += 256 * SU) {
+        half8_t v[SU];
+        int dst[SU];
+        bool keep[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            // branch-free: every lane loads from a clamped (always valid) address; a conditional load would make hipcc wait
+            // vmcnt(0) after each one (guide section 5, trap (c))
+            const int ir = i0 + u * 256;
+            const int i = ir < total ? ir : total - 1;
+            const int c = i % cpr;
+            int r = i / cpr;
+            const int pp = r % PT; r /= PT;             // pixel fastest: consecutive rows in HBM
+            const int f = r % FP;
+            const int a = r / FP;
+            dst[u] = ir < total ? a * arr_bytes + (pp * FP + f) * RS + c * 16 : -1;
+            keep[u] = f < F && pp < npix;
+            const int fc = f < F ? f : F - 1, pc = pp < npix ? pp : npix - 1;
+            const size_t tok = ((size_t)b * F + fc) * p.D + p0 + pc;
+            v[u] = *reinterpret_cast<const half8_t*>(p.qkv + tok * p.ld + a * C + col0 + c * 8);
         }
-        *reinterpret_cast<half8_t*>(smem + a * arr_bytes + (pp * FP + f) * RS + c * 16) = v;
+#pragma unroll
+        for (int u = 0; u < SU; ++u)
+            if (!keep[u]) v[u] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < SU; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<half8_t*>(smem + dst[u]) = v[u];
     }
 
     // rotary table entries of this lane: position = frame li (+16 per tile), pairs 4g .. 4g+3
