@@ -113,7 +113,7 @@ int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, v
  * ---------------------------------------------------------------------------------------------- */
 #define LAVIE_PROFILE_CLASSES 8
 /* Test/tuning knob for the implicit-GEMM kernel choice.  Low nibble: 0 automatic, 1 128-row kernel with the widest tile,
- * 2 experimental 256x160 kernel, 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
+ * 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
  * kernel, 5 halo-patch conv kernel wherever the conv is eligible, 6 automatic without the halo-patch kernel.
  * High nibble: diagnostic ablation build of the forced kernel (results wrong). */
 int lavie_debug_force_tile(int mode);

@@ -56,8 +56,6 @@ enum IgemmEpilogue { EPI_LINEAR = 0, EPI_GEGLU = 1 };
 
 // Picks a tile and launches.  Returns 0 or a negative status with lavie::set_error().
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream);
-// 256x160 phase-alternating kernel (igemm_big.hip); EPI_LINEAR only, the caller runs the split-K reduce.
-int launch_igemm_big(const IgemmParams& p, bool gather, hipStream_t stream);
 // 160x320 two-group ping-pong kernel (igemm_pp.hip); EPI_LINEAR only, N %% 320 == 0, the caller runs the split-K reduce.
 int launch_igemm_pp(const IgemmParams& p, bool gather, hipStream_t stream);
 int launch_igemm_pp_geglu(const IgemmParams& p, hipStream_t stream);   // 160x256 variant, GEGLU epilogue, N %% 256 == 0
@@ -74,7 +72,7 @@ int igemm_plan_splits_gather(const IgemmParams& p);
 int igemm_rowstat_cols(int M, int N, int nk);
 // partials [M, slots, 2] (sum, sum of squares over `row_len` values per row) -> out [M, 2] = (mean, rstd); fixed order
 int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len, float eps, float* out, hipStream_t stream);
-// Low nibble: 0 = automatic kernel / tile choice, 1 = 128-row kernel with the widest tile, 2 = experimental 256x160 kernel,
+// Low nibble: 0 = automatic kernel / tile choice, 1 = 128-row kernel with the widest tile,
 // 3 = 160x320 ping-pong kernel whenever N %% 320 == 0, 4 = automatic but never the ping-pong kernel (A/B timing),
 // 5 = halo-patch conv kernel whenever the conv is eligible, 6 = automatic but never the halo-patch kernel.
 // High nibble: diagnostic ablation build of the forced kernel (results wrong).

@@ -332,7 +332,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
 // `blocks` tiles takes ceil(blocks*S/512) rounds of (nk/S + fixed) K-steps plus a reduce pass over S slabs.
 static int g_force_tile = 0;   // see igemm_force_tile() in igemm.h
 static int g_geglu_pp_min_nk = 16;   // measured: the GEGLU epilogue (no second workgroup to hide it) loses below ~16 K-tiles
-static bool g_big_auto = false;    // flipped on once the big kernel wins on the shapes above
 static int g_force_splits = 0;
 void igemm_force_splits(int s) { g_force_splits = s; }
 
@@ -349,7 +348,7 @@ static bool pp_fits(int M, int N, int nk, int s) {
 }
 // split-K factor with which the ping-pong kernel should run this problem, 0 = do not use it
 static int pp_plan(int M, int N, int nk, int epilogue) {
-    if (epilogue != EPI_LINEAR || (g_force_tile & 0xF) == 4 || (g_force_tile & 0xF) == 1 || (g_force_tile & 0xF) == 2) return 0;
+    if (epilogue != EPI_LINEAR || (g_force_tile & 0xF) == 4 || (g_force_tile & 0xF) == 1) return 0;
     for (int s = 1; s <= 4; ++s)
         if (pp_fits(M, N, nk, s)) return s;
     return 0;
@@ -395,16 +394,6 @@ int igemm_plan_splits(int M, int N, int nk, int epilogue) {
     return best_s;
 }
 
-// Shapes for which the 256x160 phase-alternating kernel (igemm_big.hip) is used.  Filled from measurements
-// (tools/bench_ops.py): it needs a grid of at least one workgroup per CU and enough K-tiles to amortise its
-// longer prologue.
-static bool igemm_prefers_big(int M, int N, int nk, int splits) {
-    if (N % 160 != 0 || splits != 1) return false;
-    const long blocks = (long)cdiv(M, 256) * (N / 160);
-    return g_big_auto && blocks >= 256 && nk >= 8;
-}
-
-
 template <int WM, int WN, int MT, int NT, int NSTAGE, bool GATHER, int EPI, int ABL = 0>
 static int launch_tile(const IgemmParams& p, hipStream_t stream) {
     using T = IgemmTile<WM, WN, MT, NT, NSTAGE>;
@@ -427,8 +416,6 @@ static int launch_tile(const IgemmParams& p, hipStream_t stream) {
     return 0;
 }
 
-#define RUN_BIG(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
-
 // Tile width by grid quantisation: the 4-wave tiles run 2 workgroups per CU (512 slots per round); a narrower
 // tile is a little less efficient per flop (exponent 0.9) but can save a whole round on short grids.
 static int igemm_pick_bn(int M, int N, int splits) {
@@ -442,7 +429,7 @@ static int igemm_pick_bn(int M, int N, int splits) {
         if (cost < best * 0.97) { best = cost; bn = cand[i]; }
     }
     const int lo = g_force_tile & 0xF;
-    if ((lo == 1 || lo == 2 || lo == 3 || g_force_tile >= 0x10) && N % 160 == 0) bn = 160;   // forced modes: widest
+    if ((lo == 1 || lo == 3 || g_force_tile >= 0x10) && N % 160 == 0) bn = 160;   // forced modes: widest
     return bn;
 }
 
@@ -482,77 +469,49 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     LAVIE_CHECK(!(p.rowstat_out || p.ln_stats) || (p.splits == 1 && !gather), "igemm: LayerNorm folding needs a plain, unsplit GEMM");
     LAVIE_CHECK(p.splits >= 1 && p.splits <= p.nk && (p.splits == 1 || (p.slab && epilogue == EPI_LINEAR)),
                 "igemm: bad split-K setup (splits=%d)", p.splits);
-    // Tile choice.  "big": 256x160, 8 waves, 3 LDS stages (1 workgroup per CU, 2 waves per SIMD) — enough
-    // reuse that the L2->LDS stream no longer paces the MFMAs; used when the grid still fills the chip.
-    // "small": 128xBN, 4 waves, 2 stages (2 workgroups per CU) for short grids and odd N.
-    // The 256-row / 8-wave / 3-stage variant measured slower than two independent 128-row workgroups per CU on
-    // every shape of this model (its 8 waves move in lockstep); it is kept for experiments (force mode 2) only.
-    const bool big = (g_force_tile & 0xF) == 2 || ((g_force_tile & 0xF) == 0 && igemm_prefers_big(p.M, p.N, p.nk, p.splits));
+    const int lo = g_force_tile & 0xF;
+    auto reduce_splits = [&]() -> int {          // fixed-order sum of the split-K slabs + bias / residual / rounding
+        if (p.splits > 1) {
+            const long total = (long)p.M * (p.N / 4);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+            LAVIE_HIP(hipGetLastError());
+        }
+        return 0;
+    };
     if (epilogue == EPI_GEGLU) {
         LAVIE_CHECK(p.N % 128 == 0, "igemm: GEGLU needs N %% 128 == 0 (N=%d)", p.N);
         LAVIE_CHECK(!p.R && !p.bias2, "igemm: GEGLU epilogue takes no residual / per-batch bias");
         LAVIE_CHECK(!gather, "igemm: GEGLU epilogue is only built for plain A rows");
-        if (big) return launch_tile<4, 2, 4, 4, 3, false, EPI_GEGLU>(p, stream);
-        {   // 160x256 ping-pong variant: same grid rule as the 160x320 kernel, from g_geglu_pp_min_nk K-tiles on
-            const int lo = g_force_tile & 0xF;
-            const double r = (double)cdiv(p.M, 160) * (p.N / 256) / 256.0;
-            if (p.N % 256 == 0 && (lo == 3 || ((lo == 0 || lo == 6) && p.nk >= g_geglu_pp_min_nk && r / ceil(r) >= 0.85)))
-                return launch_igemm_pp_geglu(p, stream);
-        }
+        // 160x256 ping-pong variant: same grid rule as the 160x320 kernel, from g_geglu_pp_min_nk K-tiles on
+        const double r = (double)cdiv(p.M, 160) * (p.N / 256) / 256.0;
+        if (p.N % 256 == 0 && (lo == 3 || ((lo == 0 || lo == 6) && p.nk >= g_geglu_pp_min_nk && r / ceil(r) >= 0.85)))
+            return launch_igemm_pp_geglu(p, stream);
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
     }
     // halo-patch conv kernel: forced (mode 5) or whenever its grid rule holds at this split factor
-    if (gather && epilogue == EPI_LINEAR && igemm_patch_eligible(p) &&
-        ((g_force_tile & 0xF) == 5 || ((g_force_tile & 0xF) == 0 && patch_fits(p.M, p.N, p.nk, p.splits)))) {
-        RUN_BIG(launch_igemm_patch(p, stream));
-        if (p.splits > 1) {
-            const long total = (long)p.M * (p.N / 4);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
-            LAVIE_HIP(hipGetLastError());
-        }
-        return 0;
+    if (gather && igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits)))) {
+        if (int rc = launch_igemm_patch(p, stream)) return rc;
+        return reduce_splits();
     }
     // 160x320 ping-pong kernel: forced (mode 3) or whenever the planner's rule holds for this problem at its split factor
-    const bool use_pp = p.N % 320 == 0 && ((g_force_tile & 0xF) == 3 ||
-                                            (((g_force_tile & 0xF) == 0 || (g_force_tile & 0xF) == 6) && pp_fits(p.M, p.N, p.nk, p.splits)));
-    if (use_pp) {
-        RUN_BIG(launch_igemm_pp(p, gather, stream));
-        if (p.splits > 1) {
-            const long total = (long)p.M * (p.N / 4);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
-            LAVIE_HIP(hipGetLastError());
-        }
-        return 0;
+    if (p.N % 320 == 0 && (lo == 3 || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits)))) {
+        if (int rc = launch_igemm_pp(p, gather, stream)) return rc;
+        return reduce_splits();
     }
+    // 128-row kernel: two independent workgroups per CU, tile width by grid quantisation
     const int bn = igemm_pick_bn(p.M, p.N, p.splits);
     LAVIE_CHECK(bn != 0, "igemm: N=%d is not a multiple of 64", p.N);
     if (bn == 160) {
-        if (g_force_tile >= 0x10 && gather) {          // diagnostic ablations of the main conv kernel
-            switch (g_force_tile >> 4) {
-                case 1: return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 1>(p, stream);
-                case 2: return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 2>(p, stream);
-                default: return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 3>(p, stream);
-            }
-        }
-        if (g_force_tile >= 0x10 && !gather && (g_force_tile & 0xF) != 2) {   // diagnostic ablations of the small plain tile
+        if (g_force_tile >= 0x10 && lo == 1) {          // diagnostic ablations of the 128x160 tile (results wrong)
             const int abl = g_force_tile >> 4;
-            if ((g_force_tile & 0xF) == 2) {
-                if (abl == 1) return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR, 1>(p, stream);
-                if (abl == 2) return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR, 2>(p, stream);
-                return launch_tile<4, 2, 4, 5, 3, false, EPI_LINEAR, 3>(p, stream);
+            if (gather) {
+                if (abl == 1) return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 1>(p, stream);
+                if (abl == 2) return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 2>(p, stream);
+                return launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR, 3>(p, stream);
             }
             if (abl == 1) return launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR, 1>(p, stream);
             if (abl == 2) return launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR, 2>(p, stream);
             return launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR, 3>(p, stream);
-        }
-        if (big) {
-            RUN_BIG(launch_igemm_big(p, gather, stream));
-            if (p.splits > 1) {
-                const long total = (long)p.M * (p.N / 4);
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
-                LAVIE_HIP(hipGetLastError());
-            }
-            return 0;
         }
         return gather ? launch_tile<2, 2, 4, 5, 2, true, EPI_LINEAR>(p, stream)
                       : launch_tile<2, 2, 4, 5, 2, false, EPI_LINEAR>(p, stream);
@@ -564,12 +523,10 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
                   : launch_tile<2, 2, 4, 2, 2, false, EPI_LINEAR>(p, stream);
 }
 
-void igemm_big_ablate(int a);
 void igemm_pp_ablate(int a);
 void igemm_patch_set_stamp(int mode);
 void igemm_force_tile(int mode) {
     g_force_tile = mode;
-    igemm_big_ablate((mode & 0xF) == 2 ? mode >> 4 : 0);
     igemm_pp_ablate((mode & 0xF) == 3 ? mode >> 4 : 0);
     igemm_patch_set_stamp(mode == 0x75 ? 1 : mode == 0x85 ? 2 : mode == 0x95 ? 3 : mode == 0xA5 ? 4 : mode == 0xB5 ? 5 : 0);
 }

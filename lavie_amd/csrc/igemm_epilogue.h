@@ -1,4 +1,4 @@
-// Shared epilogue of the implicit-GEMM kernels (igemm.hip, igemm_big.hip).
+// Shared epilogue of the implicit-GEMM kernels (igemm.hip, igemm_pp.hip, igemm_patch.hip).
 #pragma once
 #include <type_traits>
 

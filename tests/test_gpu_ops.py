@@ -10,15 +10,15 @@ from gpu_util import TOL_OP, f32, h16, q16, rel_l2, rows, unrows
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "big-tiles", "split-k-3", "pingpong", "pingpong-split-k-2"])
+@pytest.fixture(scope="module", params=["auto", "row128-tiles", "split-k-3", "pingpong", "pingpong-split-k-2"])
 def ops(request):
-    """Every operator test runs five times: automatic choices, the 256-row / 3-stage GEMM tiles forced,
+    """Every operator test runs five times: automatic choices, the 128-row GEMM kernel forced (widest tile),
     split-K = 3 forced (fp32 slabs + fixed-order reduce) on every implicit GEMM that has >= 3 K-tiles, and the
     160x320 two-group ping-pong kernel forced (every GEMM with N % 320 == 0), alone and with split-K = 2."""
     assert torch.cuda.is_available(), "gpu tests need a HIP device"
     from lavie_amd import _lib, ops as o
     lib = _lib.load()
-    lib.lavie_debug_force_tile({"big-tiles": 2, "pingpong": 3, "pingpong-split-k-2": 3}.get(request.param, 0))
+    lib.lavie_debug_force_tile({"row128-tiles": 1, "pingpong": 3, "pingpong-split-k-2": 3}.get(request.param, 0))
     lib.lavie_debug_force_splits({"split-k-3": 3, "pingpong-split-k-2": 2}.get(request.param, 0))
     yield o
     lib.lavie_debug_force_tile(0)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-shape timing of the hot operators at the benchmark's real shapes (MI355X).  A/B over GEMM tile modes.
+"""Per-shape timing of the hot operators at the benchmark's real shapes (MI355X).  A/B over GEMM kernel modes
+(lavie_debug_force_tile: 0 automatic, 4 never the ping-pong kernel, ...).
 Usage: python tools/bench_ops.py [linear|conv|attn|all]"""
 import math
 import os
@@ -193,7 +194,7 @@ def bench_ablate_gemm():
     for M, N, K in ((20480, 640, 2560), (81920, 320, 1280), (5120, 1280, 5120)):
         a, w = rnd(M, K), rnd(N, K) / math.sqrt(K)
         out = torch.empty(M, N, dtype=torch.float16, device=dev)
-        for tile, tname in ((1, "small 128x160 2-stage"), (2, "big 256x160 3-stage")):
+        for tile, tname in ((1, "128x160 2-stage"),):
             row = f"{M}x{N}x{K} {tname:24s} | "
             for abl, name in ((0, "full"), (1, "noMFMA"), (2, "noLoads"), (3, "loadsOnly")):
                 _lib.load().lavie_debug_force_tile(abl * 16 + tile)

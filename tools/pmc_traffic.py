@@ -28,7 +28,7 @@ def classes(name):
         out.append("conv_class")
     elif "igemm_pp_kernel" in name:
         out.append("linear")
-    elif "igemm_kernel" in name or "igemm_big_kernel" in name:
+    elif "igemm_kernel" in name:
         gather = ", true," in name or "Lb1E" in name
         out.append("conv_class" if gather else "linear")
     elif "temporal_attention_kernel" in name:
