@@ -8,6 +8,7 @@ CLIP text encoding and VAE decoding are NOT part of this package's compute path:
 PyTorch-ROCm `tokenizer`/`text_encoder`/`vae` objects to use them, or work with embeddings and
 `output_type="latent"` (what the benchmark measures: video-latents/s)."""
 from dataclasses import dataclass
+import inspect
 from typing import Callable, List, Optional, Union
 
 import torch
@@ -112,12 +113,15 @@ class VideoGenPipeline:
     # ------------------------------------------------------------------ the denoise loop (662-689)
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, ctx: torch.Tensor, num_inference_steps: int, guidance_scale: float,
-                generator=None, callback: Optional[Callable] = None, callback_steps: int = 1) -> torch.Tensor:
+                generator=None, callback: Optional[Callable] = None, callback_steps: int = 1, eta: float = 0.0) -> torch.Tensor:
         """latents fp32 [P, C, F, h, w] on the device, ctx fp16 [2P, n, d] = [negative | prompt] -> denoised fp32."""
         dev = latents.device
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps)
         timesteps = [int(t) for t in sch.timesteps]
+        # `eta` goes to the scheduler only if its step takes one (DDIM), as prepare_extra_step_kwargs does
+        # (pipeline_videogen.py:431-446); DDPM ignores it
+        takes_eta = "eta" in inspect.signature(sch.coefficients).parameters
         do_cfg = guidance_scale > 1.0
         if not do_cfg:
             raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance) is outside the fused MI355X loop")
@@ -143,10 +147,10 @@ class VideoGenPipeline:
 
         for i, t in enumerate(timesteps):
             eps = self.unet(model_in, t_dev[i], encoder_hidden_states=ctx).sample      # line 670
-            coeffs = sch.coefficients(t)
+            coeffs = sch.coefficients(t, eta) if takes_eta else sch.coefficients(t)
             noise = None
             slot = i & 1
-            if t > 0:
+            if coeffs[4] != 0.0:            # the step adds noise (DDPM: every step but the last; DDIM: only with eta > 0)
                 if host_noise:
                     if copy_done[slot] is not None:
                         copy_done[slot].synchronize()
@@ -162,7 +166,7 @@ class VideoGenPipeline:
                 else:
                     noise = noise_dev.normal_(generator=generator) if generator is not None else noise_dev.normal_()
             ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs)           # lines 679-683 fused
-            if host_noise and t > 0:
+            if host_noise and coeffs[4] != 0.0:
                 step_done[slot] = torch.cuda.Event()
                 step_done[slot].record(main)
             if callback is not None and i % callback_steps == 0:
@@ -192,7 +196,7 @@ class VideoGenPipeline:
                                   negative_prompt_embeds).to(torch.float16).contiguous()
         latents = self.prepare_latents(batch_size * num_images_per_prompt, self.unet.config.in_channels, video_length,
                                        height, width, torch.float32, device, generator, latents)
-        latents = self.denoise(latents, ctx, num_inference_steps, guidance_scale, generator, callback, callback_steps)
+        latents = self.denoise(latents, ctx, num_inference_steps, guidance_scale, generator, callback, callback_steps, eta)
         if output_type == "latent":
             video = latents
         else:

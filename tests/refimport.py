@@ -30,3 +30,16 @@ def load():
         spec.loader.exec_module(mod)
         setattr(pkg, name, mod)
     return pkg
+
+
+def load_vsr_ddim():
+    """The reference's vendored DDIM scheduler class (vsr/diffusion/scheduling_ddim.py) under the shim."""
+    if "ref_vsr_ddim" in sys.modules:
+        return sys.modules["ref_vsr_ddim"].DDIMScheduler
+    if _SHIM not in sys.path:
+        sys.path.insert(0, _SHIM)
+    spec = importlib.util.spec_from_file_location("ref_vsr_ddim", "/root/reference/vsr/diffusion/scheduling_ddim.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_vsr_ddim"] = mod
+    spec.loader.exec_module(mod)
+    return mod.DDIMScheduler

@@ -18,3 +18,13 @@ logging = _Logging()
 
 def deprecate(*a, **k):
     pass
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+    """diffusers.utils.randn_tensor contract: a CPU generator draws on the CPU, the result is moved."""
+    import torch
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    gen_dev = generator.device.type if generator is not None else device.type
+    if gen_dev == "cpu" and device.type != "cpu":
+        return torch.randn(shape, generator=generator, dtype=dtype).to(device)
+    return torch.randn(shape, generator=generator, device=device, dtype=dtype)

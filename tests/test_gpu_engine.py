@@ -311,3 +311,34 @@ def test_pipeline_call_surface(small):
     assert rel_l2(outs[0], ref) < 3e-2
     with pytest.raises(ValueError):
         pipe(prompt="a horse", height=64, width=64)            # no text encoder attached
+
+
+def test_pipeline_ddim_scheduler(small):
+    """sample_method 'ddim' (base/pipelines/sample.py:44-49): the fused CFG + scheduler-step kernel driven by DDIM
+    coefficients, eta = 0 (no noise drawn) and eta = 0.6 (host noise), against the oracle loop with oracle/ddim.py."""
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    from lavie_amd.scheduling_ddim import DDIMScheduler
+    from oracle import unet_fp32 as O
+    from oracle.ddim import DDIMSchedule
+    net, sd = small
+    pipe = VideoGenPipeline(unet=net, scheduler=DDIMScheduler())
+    g = torch.Generator().manual_seed(19)
+    pe, ne = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    lat = torch.randn(1, 4, 4, 8, 8, generator=g)
+    ctx = torch.cat([ne, pe]).half().float()
+    for eta in (0.0, 0.6):
+        seen = []
+        out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=64, width=64, video_length=4,
+                   num_inference_steps=4, guidance_scale=7.5, eta=eta, generator=torch.Generator().manual_seed(5),
+                   output_type="latent", callback=lambda i, t, x: seen.append(t)).video.float().cpu()
+        assert seen == [751, 501, 251, 1]
+        osch = DDIMSchedule()
+        osch.set_timesteps(4)
+        gen = torch.Generator().manual_seed(5)
+        x = lat.clone()
+        for t in osch.timesteps:
+            eps = O.unet_forward(sd, torch.cat([x, x]), t, ctx, ocfg_small())
+            guided = eps[0:1] + 7.5 * (eps[1:2] - eps[0:1])
+            z = torch.randn(lat.shape, generator=gen) if eta > 0 else None
+            x = osch.step(guided, t, x, eta=eta, noise=z)
+        assert rel_l2(out, x) < 3e-2, eta

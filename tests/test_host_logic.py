@@ -158,3 +158,34 @@ def test_product_never_imports_oracle_or_reference():
         p = os.path.join(ROOT, f)
         if os.path.exists(p):
             assert "refimport" not in open(p).read()
+
+
+def test_ddim_scheduler_matches_oracle_and_fused_form():
+    """lavie_amd.scheduling_ddim: step == oracle step, and the five fused-kernel coefficients reproduce it."""
+    from lavie_amd.scheduling_ddim import DDIMScheduler
+    from oracle.ddim import DDIMSchedule
+    sch, osch = DDIMScheduler(), DDIMSchedule()
+    sch.set_timesteps(50)
+    osch.set_timesteps(50)
+    assert [int(t) for t in sch.timesteps] == osch.timesteps
+    assert sch.init_noise_sigma == 1.0 and sch.order == 1
+    g = torch.Generator().manual_seed(3)
+    for t in (981, 501, 21, 1):
+        for eta in (0.0, 0.7):
+            x, eps, z = (torch.randn(1, 4, 2, 8, 8, generator=g) for _ in range(3))
+            want = osch.step(eps, t, x, eta=eta, noise=z)
+            got = sch.step(eps, t, x, eta=eta, variance_noise=z if eta > 0 else None).prev_sample
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+            k_x, k_e, c0, ct, sigma = sch.coefficients(t, eta)
+            x0 = k_x * x - k_e * eps
+            fused = c0 * x0 + ct * x + sigma * z
+            assert torch.allclose(fused, want, rtol=1e-4, atol=1e-5), (t, eta)
+    vsr = DDIMScheduler(timestep_spacing="vsr_linspace")
+    ovsr = DDIMSchedule(timestep_spacing="vsr_linspace")
+    vsr.set_timesteps(50)
+    ovsr.set_timesteps(50)
+    assert [int(t) for t in vsr.timesteps] == ovsr.timesteps
+    with pytest.raises(ValueError):
+        DDIMScheduler().coefficients(981)                # set_timesteps not called
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(clip_sample=True)

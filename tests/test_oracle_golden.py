@@ -70,3 +70,24 @@ def test_ddpm_three_steps(full_sd):
     got = cfg_denoise_loop(fn, fx["latents"], fx["prompt"].float(), fx["negative"].float(), fx["noises"],
                            num_steps=50, guidance_scale=7.5, max_steps=3)
     assert rel_l2(got, fx["y"]) < 1e-4
+
+
+def test_ddim_steps_match_reference_fixture():
+    """oracle/ddim.py against outputs of the reference's vendored DDIMScheduler (tests/golden/ddim_steps.pt)."""
+    from oracle.ddim import DDIMSchedule
+    fx = G.load("ddim_steps.pt")
+    sch = DDIMSchedule()
+    sch.set_timesteps(50)
+    assert torch.allclose(sch.alphas_cumprod, fx["alphas_cumprod"], rtol=0, atol=0)
+    assert sch.timesteps[:3] == [981, 961, 941] and sch.timesteps[-1] == 1          # stock "leading" spacing + offset
+    vsr = DDIMSchedule(timestep_spacing="vsr_linspace")
+    vsr.set_timesteps(50)
+    assert vsr.timesteps == [int(t) for t in fx["vsr_timesteps_50"]]
+    for c in fx["cases"]:
+        got = sch.step(c["eps"], c["t"], c["x"], eta=c["eta"], noise=c["noise"])
+        assert rel_l2(got, c["prev"]) < 1e-6, (c["t"], c["eta"])
+    ch = fx["chain"]
+    x = ch["x"]
+    for t in ch["timesteps"]:
+        x = sch.step(torch.tanh(x * 0.7 + 0.01 * t / 1000.0), t, x)
+    assert rel_l2(x, ch["y"]) < 1e-6

@@ -121,3 +121,20 @@ def test_transformer3d_block_order():
         ref = tr(x, encoder_hidden_states=ctx, use_image_num=0).sample
         got = O.transformer3d(sd, "t.", x, ctx, O.UNetConfig())
     assert rel_l2(got, ref) < 1e-5
+
+
+def test_ddim_oracle_matches_vendored_reference_scheduler():
+    """oracle/ddim.py vs the reference's own DDIMScheduler text (vsr/diffusion/scheduling_ddim.py), every 7th step."""
+    from oracle.ddim import DDIMSchedule
+    ref = refimport.load_vsr_ddim()(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, beta_schedule="linear",
+                                    clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    ref.set_timesteps(50)
+    sch = DDIMSchedule(timestep_spacing="vsr_linspace")
+    sch.set_timesteps(50)
+    assert sch.timesteps == [int(t) for t in ref.timesteps]
+    g = torch.Generator().manual_seed(77)
+    for t in sch.timesteps[1::7]:        # [0] is 1001 with this spacing: past the alpha table in the reference as well
+        x, eps, z = (torch.randn(2, 4, 3, 8, 8, generator=g) for _ in range(3))
+        for eta in (0.0, 1.0):
+            want = ref.step(eps, t, x, eta=eta, variance_noise=z if eta > 0 else None).prev_sample
+            assert rel_l2(sch.step(eps, t, x, eta=eta, noise=z), want) < 1e-6
