@@ -85,6 +85,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C lavie_amd/csrc).  lavie_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so and the library links the same SONAME.
+    # Whichever copy is loaded first serves both; if this library came first (its /opt/rocm copy) and torch later
+    # loaded its own, the two runtimes would not see each other's device (hipMalloc: "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -206,7 +206,7 @@ const half_t* UNet::given(const std::string& name) const {
 #define WALLOC(var, type, count)                                                                  \
     do {                                                                                          \
         (var) = (type*)weights_.alloc((size_t)(count) * sizeof(type));                            \
-        LAVIE_CHECK((var) != nullptr, "finalize: out of device memory (%zu B)", (size_t)(count) * sizeof(type)); \
+        LAVIE_CHECK((var) != nullptr, "finalize: out of device memory (%zu B; hip: %s)", (size_t)(count) * sizeof(type), hipGetErrorString(hipGetLastError())); \
     } while (0)
 
 int UNet::pack_norm(const std::string& prefix, int C, NormW* out, hipStream_t s) {
