@@ -19,6 +19,8 @@
 // Restrictions (the launcher falls back otherwise): every K segment has 9 taps (a fused 1x1 shortcut runs as its own
 // GEMM whose result comes back through the residual operand), stride 1, no upsample, M % 320 == 0, W % 8 == 0,
 // 320 % W == 0, tile = part of one frame or whole frames, patch <= 448 rows, split-K only at slab boundaries.
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 #include "igemm.h"
@@ -359,8 +361,10 @@ int launch_igemm_patch(const IgemmParams& p, hipStream_t stream) {
     }
     const int grid = (p.M / BM) * (p.N / BN);
     const double K = (double)p.nk * IGEMM_BK;
-    ProfileScope prof(KC_CONV_PATCH, stream, 2.0 * p.M * p.N * K, 2.0 * ((double)p.M * K / 9.0 + (double)p.N * K + (double)p.M * p.N));
-    hipLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(THREADS), LDS_BYTES, stream, p);
+    ProfileScope prof(KC_CONV_PATCH, stream, 2.0 * p.M * p.N * K, 2.0 * ((double)p.M * K / 9.0 + (double)p.N * K + (double)p.M * p.N),
+                      /*kernel_events=*/true);
+    if (prof.active()) hipExtLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(THREADS), LDS_BYTES, stream, prof.start(), prof.stop(), 0, p);
+    else hipLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(THREADS), LDS_BYTES, stream, p);
     LAVIE_HIP(hipGetLastError());
     return 0;
 }

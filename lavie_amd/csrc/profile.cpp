@@ -28,18 +28,22 @@ int profile_begin(unsigned mask, int max_events) {
     return 0;
 }
 
-ProfileScope::ProfileScope(int cls, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
+ProfileScope::ProfileScope(int cls, hipStream_t s, double flops, double bytes, bool kernel_events_)
+    : slot(-1), stream(s), kernel_events(kernel_events_) {
     if (!profile_enabled(cls) || g_next + 2 > g_pool.size()) return;
     Rec r{g_pool[g_next], g_pool[g_next + 1], cls, flops, bytes};
     g_next += 2;
-    if (hipEventRecord(r.a, s) != hipSuccess) return;
+    if (!kernel_events && hipEventRecord(r.a, s) != hipSuccess) return;
     slot = (int)g_recs.size();
     g_recs.push_back(r);
 }
 
 ProfileScope::~ProfileScope() {
-    if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, stream);
+    if (slot >= 0 && !kernel_events) (void)hipEventRecord(g_recs[slot].b, stream);
 }
+
+hipEvent_t ProfileScope::start() const { return g_recs[slot].a; }
+hipEvent_t ProfileScope::stop() const { return g_recs[slot].b; }
 
 int profile_end(hipStream_t stream, long long* launches, double* ms, double* flops, double* bytes) {
     g_mask = 0;

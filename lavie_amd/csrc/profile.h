@@ -18,10 +18,17 @@ enum KernelClass {
 };
 
 struct ProfileScope {
-    ProfileScope(int cls, hipStream_t s, double flops, double bytes);
+    // kernel_events = false: the scope brackets everything enqueued during its lifetime with two hipEventRecord calls
+    // (~11 us of stream time per scope).  kernel_events = true: nothing is recorded here; the launcher passes start() /
+    // stop() to hipExtLaunchKernelGGL, which stamps them with that ONE kernel's own begin / end (no extra packets).
+    ProfileScope(int cls, hipStream_t s, double flops, double bytes, bool kernel_events = false);
     ~ProfileScope();
+    bool active() const { return slot >= 0; }
+    hipEvent_t start() const;
+    hipEvent_t stop() const;
     int slot;
     hipStream_t stream;
+    bool kernel_events;
 };
 
 // mask: bit i enables class i.  Returns 0.

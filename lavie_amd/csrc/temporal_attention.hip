@@ -18,6 +18,8 @@
 //    MFMA 16x16x16 for O^T = V^T P^T with P^T taken straight from the accumulator registers;
 //  * O overwrites the wave's own Q slots in LDS and the whole tile is stored coalesced.
 // Algorithmic HBM bytes per launch: 4 * tokens * C * 2 (q, k, v read + o write).
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "ops.h"
 #include "profile.h"
@@ -248,7 +250,7 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
     LAVIE_CHECK(p.ld % 8 == 0 && p.ldo % 8 == 0, "temporal attention: row strides must be multiples of 8 halfs");
     const double tok = (double)p.B * p.F * p.D, width = (double)p.heads * p.dh;
     // algorithmic bytes: q, k, v read + o written once: 4 * tokens * C * 2 B
-    ProfileScope prof(KC_TEMPORAL, stream, 4.0 * tok * p.F * width, 4.0 * tok * width * 2.0);
+    ProfileScope prof(KC_TEMPORAL, stream, 4.0 * tok * p.F * width, 4.0 * tok * width * 2.0, /*kernel_events=*/true);
     const int NT = cdiv(p.F, 16) <= 1 ? 1 : 4;
     const int FP = NT * 16;
     // pick (HG, PT): the largest tile whose three LDS arrays stay under the budget.  Rows are padded to 32 B x odd
@@ -278,14 +280,16 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
             LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_attention_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr1 = true;
         }
-        hipLaunchKernelGGL(temporal_attention_kernel<1>, dim3(grid), dim3(256), gm.lds_bytes, stream, p, gm);
+        if (prof.active()) hipExtLaunchKernelGGL(temporal_attention_kernel<1>, dim3(grid), dim3(256), gm.lds_bytes, stream, prof.start(), prof.stop(), 0, p, gm);
+        else hipLaunchKernelGGL(temporal_attention_kernel<1>, dim3(grid), dim3(256), gm.lds_bytes, stream, p, gm);
     } else {
         static bool attr4 = false;
         if (!attr4) {
             LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr4 = true;
         }
-        hipLaunchKernelGGL(temporal_attention_kernel<4>, dim3(grid), dim3(256), gm.lds_bytes, stream, p, gm);
+        if (prof.active()) hipExtLaunchKernelGGL(temporal_attention_kernel<4>, dim3(grid), dim3(256), gm.lds_bytes, stream, prof.start(), prof.stop(), 0, p, gm);
+        else hipLaunchKernelGGL(temporal_attention_kernel<4>, dim3(grid), dim3(256), gm.lds_bytes, stream, p, gm);
     }
     LAVIE_HIP(hipGetLastError());
     return 0;
