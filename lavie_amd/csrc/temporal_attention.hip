@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
     // ---- stage q | k | v : piece = (array a, pixel pp, frame f, 16-B chunk c)
     const int cpr = RL >> 3;                        // chunks per row
     const int total = 3 * PT * FP * cpr;
-    // Eight pieces per thread and pass: all eight 16-B loads are issued before the first LDS store, so a pass costs one
-    // memory latency instead of eight (the kernel has no compute to hide loads under; a one-piece loop serialised them).
-    constexpr int SU = 8;
+    // SU pieces per thread and pass: all their 16-B loads are issued before the first LDS store, so a pass costs one
+    // memory latency instead of SU (the kernel has no compute to hide loads under; a one-piece loop serialised them).
+    constexpr int SU = 8;                         // (16 measured slower: 121 VGPRs cost more occupancy than one latency saves)
     for (int i0 = tid; i0 < total; i0 += 256 * SU) {
         half8_t v[SU];
         int dst[SU];
