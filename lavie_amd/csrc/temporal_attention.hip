@@ -107,13 +107,25 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
             rc[t][j] = ok ? p.rot_cos[f * rpairs + k] : 1.f;
             rs[t][j] = ok ? p.rot_sin[f * rpairs + k] : 0.f;
         }
+    // relative-position bias of this lane's (query li, keys 4g..4g+3) for the wave's first two pairs: one 16-B load each,
+    // issued while the staging loads are still in flight (inside the compute loop it is a dependent L2 round trip per pair)
+    const bool bias_vec = NT == 1 && (F & 3) == 0;
+    f32x4 bpre0 = {0.f, 0.f, 0.f, 0.f}, bpre1 = {0.f, 0.f, 0.f, 0.f};
+    if (bias_vec) {
+        const int qic = li < F ? li : F - 1;
+        const int kc = 4 * g < F ? 4 * g : F - 4;
+        const int h0 = hg * HG + wave % HG, h1 = hg * HG + (wave + 4) % HG;
+        bpre0 = *reinterpret_cast<const f32x4*>(p.bias + ((size_t)h0 * F + qic) * F + kc);
+        bpre1 = *reinterpret_cast<const f32x4*>(p.bias + ((size_t)h1 * F + qic) * F + kc);
+    }
     __syncthreads();
 
     const int KS = (dh + 31) >> 5;
     const int DT = (dh + 15) >> 4;
     const float l2e = 1.4426950408889634f;
 
-    for (int pair = wave; pair < npix * HG; pair += 4) {
+    int pair_no = 0;
+    for (int pair = wave; pair < npix * HG; pair += 4, ++pair_no) {
         const int pp = pair / HG, hl = pair - pp * HG;
         const int h = hg * HG + hl;
         const int rowbase = pp * FP;
@@ -176,7 +188,11 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = -INFINITY;
-                    if (kj + r < F) v = (s[kt][qt][r] + p.bias[((size_t)h * F + qic) * F + kj + r]) * l2e;
+                    if (kj + r < F) {
+                        const float bias_v = (bias_vec && pair_no < 2) ? (pair_no == 0 ? bpre0[r] : bpre1[r])
+                                                                     : p.bias[((size_t)h * F + qic) * F + kj + r];
+                        v = (s[kt][qt][r] + bias_v) * l2e;
+                    }
                     s[kt][qt][r] = v;
                     mx = fmaxf(mx, v);
                 }
