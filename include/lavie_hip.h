@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAVIE_ABI_VERSION 1
+#define LAVIE_ABI_VERSION 2
 #define LAVIE_MAX_LEVELS 8
 
 const char* lavie_last_error(void);
@@ -85,9 +85,18 @@ int lavie_layer_norm_f16(const void* x, const float* gamma, const float* beta, v
 int lavie_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int NB,
                         int Lq, int Lk, int heads, int dh, int kv_batch_div, float scale, void* stream);
 
+/* SparseCausalAttention (interpolation/models/attention.py:609-665): spatial self-attention whose keys/values for
+ * frame f of a video are the D tokens of the video's FIRST frame followed by the D tokens of frame max(f-1, 0)
+ * (:630-639), i.e. 2 D keys per query; the concatenation is never materialised — the kernel stages both segments
+ * straight from the per-frame K/V rows.  q/k/v/o: [NB*D, ld] rows, NB = videos * frames, NB %% frames == 0. */
+int lavie_sparse_causal_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
+                                      int ldo, int NB, int frames, int D, int heads, int dh, float scale, void* stream);
+
 /* TemporalAttention._attention (attention.py:634-667) on tokens ordered (b, f, pixel):
  * qkv [B*F*D, ld] = q | k | v, o [B*F*D, ldo]; bias [heads, F, F] fp32 (query, key);
- * rot_cos/rot_sin [F, rot_dim/2] fp32. */
+ * rot_cos/rot_sin [F, rot_dim/2] fp32.  rot_dim = 0 (tables may be NULL) and an all-zero bias give the plain
+ * softmax(scale q k^T) v over frames of the interpolation model's attn_temp (interpolation/models/attention.py:
+ * 268-289, 596-603). */
 int lavie_temporal_attention_f16(const void* qkv, int ld, void* o, int ldo, int B, int F, int D, int heads, int dh,
                                  const float* bias, const float* rot_cos, const float* rot_sin, int rot_dim, float scale,
                                  void* stream);
@@ -148,6 +157,12 @@ typedef struct lavie_unet_config {
     float norm_eps;
     int rotary_dim;
     int rel_buckets, rel_max_distance;
+    /* Block variant of the frame-interpolation model (interpolation/models/attention.py:456-606; all 0 = base model):
+     *   sparse_causal_attn1 : attn1 is SparseCausalAttention (use_first_frame, :493-504, 609-665)
+     *   temporal_plain      : attn_temp is the plain CrossAttention over frames — no rotary embedding, no
+     *                         relative-position bias, and no such tensors in the state dict (:525-533)
+     *   ff_before_temporal  : block order spatial -> text -> feed-forward -> temporal (:566-606) */
+    int sparse_causal_attn1, temporal_plain, ff_before_temporal;
 } lavie_unet_config;
 
 int lavie_unet_create(const lavie_unet_config* cfg, lavie_unet_t* out);

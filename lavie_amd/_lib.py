@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LEVELS = 8
 
 c_void_p, c_int, c_float, c_ll, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_char_p
@@ -20,6 +20,7 @@ class UNetConfigC(C.Structure):
         ("block_out_channels", c_int * MAX_LEVELS), ("attn_levels", c_int * MAX_LEVELS),
         ("layers_per_block", c_int), ("heads", c_int), ("cross_attention_dim", c_int), ("norm_groups", c_int),
         ("norm_eps", c_float), ("rotary_dim", c_int), ("rel_buckets", c_int), ("rel_max_distance", c_int),
+        ("sparse_causal_attn1", c_int), ("temporal_plain", c_int), ("ff_before_temporal", c_int),
     ]
 
 
@@ -40,6 +41,8 @@ SIGNATURES = {
     "lavie_layer_norm_f16": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "lavie_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_void_p]),
+    "lavie_sparse_causal_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                                   c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "lavie_temporal_attention_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float_p,
                                               c_float_p, c_float_p, c_int, c_float, c_void_p]),
     "lavie_relpos_buckets": (c_int, [c_int, c_int, c_int, C.POINTER(c_int)]),
@@ -99,7 +102,7 @@ def load():
             raise
         fn.restype = res
         fn.argtypes = args
-    if lib.lavie_abi_version() != ABI_VERSION:
+    if lib.lavie_abi_version() != ABI_VERSION and not os.environ.get("LAVIE_HIP_LIB"):
         raise RuntimeError(f"liblavie_hip.so ABI {lib.lavie_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib

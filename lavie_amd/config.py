@@ -20,6 +20,10 @@ class UNetConfig:
     rel_buckets: int = 32                # RelativePositionBias(num_buckets=32, max_distance=32), attention.py:577
     rel_max_distance: int = 32
     attn_levels: Tuple[bool, ...] = field(default=(True, True, True, False))
+    # Block variant of the frame-interpolation model (interpolation/models/attention.py:456-606, unet.py:477-506)
+    sparse_causal_attn1: bool = False    # use_first_frame: attn1 keys/values = first frame || previous frame
+    temporal_plain: bool = False         # attn_temp without rotary embedding / relative-position bias
+    ff_before_temporal: bool = False     # block order spatial -> text -> FF -> temporal
 
     @property
     def time_embed_dim(self) -> int:
@@ -34,10 +38,14 @@ class UNetConfig:
                 raise ValueError(f"channel width {c} must be a multiple of 64 (K-tile of the MFMA kernels)")
             if c % self.norm_groups != 0:
                 raise ValueError(f"channel width {c} not divisible by {self.norm_groups} groups")
-            if a and (c % self.heads != 0 or c // self.heads < self.rotary_dim or (c // self.heads) % 8 != 0):
+            min_dh = 8 if self.temporal_plain else self.rotary_dim
+            if a and (c % self.heads != 0 or c // self.heads < min_dh or (c // self.heads) % 8 != 0):
                 raise ValueError(f"width {c}: head dim must be a multiple of 8 and >= rotary_dim")
         if self.cross_attention_dim % 64 != 0:
             raise ValueError("cross_attention_dim must be a multiple of 64")
 
 
 BASE_CONFIG = UNetConfig()
+# `from_pretrained_2d(..., use_concat=True, copy_no_mask=True)` of the interpolation stage (interpolation/models/unet.py:
+# 477-506, interpolation/configs/sample.yaml): noisy latent || copied low-frame-rate latent on 8 input channels
+INTERPOLATION_CONFIG = UNetConfig(in_channels=8, sparse_causal_attn1=True, temporal_plain=True, ff_before_temporal=True)

@@ -134,10 +134,21 @@ int lavie_attention_f16(const void* q, int ldq, const void* k, int ldk, const vo
     return launch_attention(a, S(stream));
 }
 
+int lavie_sparse_causal_attention_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o,
+                                      int ldo, int NB, int frames, int D, int heads, int dh, float scale, void* stream) {
+    LAVIE_CHECK(q && k && v && o, "sparse-causal attention: null tensor");
+    LAVIE_CHECK(frames >= 1 && NB >= frames && NB % frames == 0 && D >= 1, "sparse-causal attention: NB=%d frames=%d D=%d", NB, frames, D);
+    AttnParams a;
+    a.q = H(q); a.ldq = ldq; a.k = H(k); a.ldk = ldk; a.v = H(v); a.ldv = ldv; a.o = H(o); a.ldo = ldo;
+    a.NBq = NB; a.Lq = D; a.Lk = 2 * D; a.heads = heads; a.dh = dh; a.kv_batch_div = 1; a.scale = scale;
+    a.sc_frames = frames;
+    return launch_attention(a, S(stream));
+}
+
 int lavie_temporal_attention_f16(const void* qkv, int ld, void* o, int ldo, int B, int F, int D, int heads, int dh,
                                  const float* bias, const float* rot_cos, const float* rot_sin, int rot_dim, float scale,
                                  void* stream) {
-    LAVIE_CHECK(qkv && o && bias && rot_cos && rot_sin, "temporal attention: null tensor");
+    LAVIE_CHECK(qkv && o && bias && (rot_dim == 0 || (rot_cos && rot_sin)), "temporal attention: null tensor");
     TemporalParams t;
     t.qkv = H(qkv); t.ld = ld; t.o = H(o); t.ldo = ldo; t.B = B; t.F = F; t.D = D; t.heads = heads; t.dh = dh;
     t.bias = bias; t.rot_cos = rot_cos; t.rot_sin = rot_sin; t.rot_dim = rot_dim; t.scale = scale;

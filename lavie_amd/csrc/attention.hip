@@ -40,7 +40,9 @@ struct AttTile {
 // staging never writes; it lies inside the last 16-wide output tile whenever dh % 16 != 0) holds 1.0, so output
 // dimension dh accumulates sum_k p[q, k] on the matrix pipe and is rescaled together with O — 16 v_add_f32 per query
 // tile and key tile less on the VALU, which paces this kernel at head dim 40.
-template <int DHP, int QT, int ABL = 0, bool LSUM = false>
+// SC: sparse-causal key/value addressing (AttnParams::sc_frames): key j of batch entry (b, f) is token j % D of frame
+// (b, 0) for j < D and of frame (b, max(f-1, 0)) for j >= D — a per-piece row lookup in the staging loads, nothing else.
+template <int DHP, int QT, int ABL = 0, bool LSUM = false, bool SC = false>
 __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention_kernel(const AttnParams p) {
     using T = AttTile<DHP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,8 +87,13 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
         }
     }
 
-    const half_t* kbase = p.k + (size_t)kvb * p.Lk * p.ldk + head * dh;
-    const half_t* vbase = p.v + (size_t)kvb * p.Lk * p.ldv + head * dh;
+    const half_t* kbase = p.k + (SC ? (size_t)0 : (size_t)kvb * p.Lk * p.ldk) + head * dh;
+    const half_t* vbase = p.v + (SC ? (size_t)0 : (size_t)kvb * p.Lk * p.ldv) + head * dh;
+    // sparse-causal: first token row of the two key segments of this batch entry
+    const int sc_D = p.Lk >> 1;
+    const int sc_f = SC ? qb % p.sc_frames : 0;
+    const int sc_row0 = (qb - sc_f) * sc_D;
+    const int sc_row1 = (qb - (sc_f > 0 ? 1 : 0)) * sc_D - sc_D;      // row of key j >= D is sc_row1 + j
     // staging plan of this thread, fixed for the whole loop (no per-tile index arithmetic): piece i covers
     // 16 bytes of key `pkey[i]` of the tile; a negative key marks an unused slot
     const int npiece = ATT_KEYS * nch;
@@ -99,8 +106,8 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
         const int key = pc / nch, c = pc - key * nch;
         pkey[i] = pc < npiece ? key : -(1 << 30);
         lofs[i] = key * T::STRIDE + c * 16;
-        kofs_g[i] = (size_t)key * p.ldk + c * 8;
-        vofs_g[i] = (size_t)key * p.ldv + c * 8;
+        kofs_g[i] = SC ? (size_t)(c * 8) : (size_t)key * p.ldk + c * 8;
+        vofs_g[i] = SC ? (size_t)(c * 8) : (size_t)key * p.ldv + c * 8;
     }
 
     auto load_tile = [&](int key0) {
@@ -110,8 +117,15 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
         for (int i = 0; i < T::MAXPIECE; ++i) {
             if (pkey[i] >= 0) {
                 if (key0 + pkey[i] < p.Lk) {
-                    rk[i] = *reinterpret_cast<const half8_t*>(kt0 + kofs_g[i]);
-                    rv[i] = *reinterpret_cast<const half8_t*>(vt0 + vofs_g[i]);
+                    if constexpr (SC) {
+                        const int j = key0 + pkey[i];
+                        const size_t row = (size_t)(j < sc_D ? sc_row0 + j : sc_row1 + j);
+                        rk[i] = *reinterpret_cast<const half8_t*>(kbase + row * p.ldk + kofs_g[i]);
+                        rv[i] = *reinterpret_cast<const half8_t*>(vbase + row * p.ldv + vofs_g[i]);
+                    } else {
+                        rk[i] = *reinterpret_cast<const half8_t*>(kt0 + kofs_g[i]);
+                        rv[i] = *reinterpret_cast<const half8_t*>(vt0 + vofs_g[i]);
+                    }
                 } else {
                     rk[i] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
                     rv[i] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
@@ -303,10 +317,10 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
     }
 }
 
-template <int DHP, int QT, int ABL = 0, bool LSUM = false>
+template <int DHP, int QT, int ABL = 0, bool LSUM = false, bool SC = false>
 static int launch_att(const AttnParams& p, hipStream_t stream) {
     using T = AttTile<DHP>;
-    auto kern = attention_kernel<DHP, QT, ABL, LSUM>;
+    auto kern = attention_kernel<DHP, QT, ABL, LSUM, SC>;
     static bool attr_set = false;
     if (!attr_set) {
         LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
@@ -329,6 +343,21 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
     ProfileScope prof(KC_ATTENTION, stream, 4.0 * tok_q * p.Lk * width,
                       2.0 * (2.0 * tok_q * width + 2.0 * ((double)p.NBq / p.kv_batch_div) * p.Lk * width));
     const bool big = p.Lq > 64 * 3;     // >= 2 full 128-row blocks: use 32 rows per wave
+    if (p.sc_frames > 0) {
+        LAVIE_CHECK(p.Lk == 2 * p.Lq && p.kv_batch_div == 1 && p.NBq % p.sc_frames == 0,
+                    "sparse-causal attention: needs Lk = 2 Lq, kv_batch_div = 1, NB %% frames = 0 (Lq=%d Lk=%d NB=%d frames=%d)",
+                    p.Lq, p.Lk, p.NBq, p.sc_frames);
+        const bool ls = p.dh % 16 != 0;
+        if (p.dh <= 64) {
+            if (ls) return big ? launch_att<64, 2, 0, true, true>(p, stream) : launch_att<64, 1, 0, true, true>(p, stream);
+            return big ? launch_att<64, 2, 0, false, true>(p, stream) : launch_att<64, 1, 0, false, true>(p, stream);
+        }
+        if (p.dh <= 96) {
+            if (ls) return big ? launch_att<96, 2, 0, true, true>(p, stream) : launch_att<96, 1, 0, true, true>(p, stream);
+            return big ? launch_att<96, 2, 0, false, true>(p, stream) : launch_att<96, 1, 0, false, true>(p, stream);
+        }
+        return big ? launch_att<160, 2, 0, false, true>(p, stream) : launch_att<160, 1, 0, false, true>(p, stream);
+    }
     if (g_force_qt == 0x12 && p.dh <= 64) return launch_att<64, 2, 1>(p, stream);
     if (g_force_qt == 0x22 && p.dh <= 64) return launch_att<64, 2, 2>(p, stream);
     if (g_force_qt == 0x32 && p.dh <= 64) return launch_att<64, 2, 3>(p, stream);

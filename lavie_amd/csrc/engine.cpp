@@ -87,11 +87,13 @@ int UNet::validate_config() {
         const int w = c.block_out_channels[l];
         LAVIE_CHECK(w % 64 == 0 && w % c.norm_groups == 0, "config: width %d must be a multiple of 64 and of norm_groups", w);
         if (c.attn_levels[l]) {
-            LAVIE_CHECK(w % c.heads == 0 && (w / c.heads) % 8 == 0 && w / c.heads >= c.rotary_dim && w / c.heads <= 160,
-                        "config: width %d gives head dim %d (need multiple of 8, %d..160)", w, w / c.heads, c.rotary_dim);
+            const int min_dh = c.temporal_plain ? 8 : c.rotary_dim;
+            LAVIE_CHECK(w % c.heads == 0 && (w / c.heads) % 8 == 0 && w / c.heads >= min_dh && w / c.heads <= 160,
+                        "config: width %d gives head dim %d (need multiple of 8, %d..160)", w, w / c.heads, min_dh);
         }
     }
     LAVIE_CHECK(c.rotary_dim == 32 || c.rotary_dim == 16 || c.rotary_dim == 8, "config: rotary_dim %d", c.rotary_dim);
+    LAVIE_CHECK(c.in_channels % 2 == 0, "config: in_channels %d must be even (conv_in packs channel pairs)", c.in_channels);
     return 0;
 }
 
@@ -133,8 +135,10 @@ void UNet::build_param_list() {
         attention(b + ".attn2", ch, c.cross_attention_dim);
         affine(b + ".norm2", ch);
         attention(b + ".attn_temp", ch, ch);
-        add(b + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight", {c.rel_buckets, c.heads});
-        add(b + ".attn_temp.rotary_emb.freqs", {c.rotary_dim / 2});
+        if (!c.temporal_plain) {
+            add(b + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight", {c.rel_buckets, c.heads});
+            add(b + ".attn_temp.rotary_emb.freqs", {c.rotary_dim / 2});
+        }
         affine(b + ".norm_temp", ch);
         lin(b + ".ff.net.0.proj", ch, 8 * ch, true);
         lin(b + ".ff.net.2", 4 * ch, ch, true);
@@ -306,7 +310,7 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
     RUN(pack_linear(b + ".attn2.to_out.0", C, C, true, &t->o2, s));
     RUN(fuse(b + ".attn_temp", qkv, 3, C, &t->wqkvt));
     RUN(pack_linear(b + ".attn_temp.to_out.0", C, C, true, &t->ot, s));
-    {
+    if (!cfg_.temporal_plain) {
         const std::string key = b + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight";
         const half_t* e = given(key);
         NEED(e, key);
@@ -428,9 +432,18 @@ int UNet::ensure_tables(int F, hipStream_t s) {
     LAVIE_HIP(hipMemcpy(rot_cos_, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice));
     LAVIE_HIP(hipMemcpy(rot_sin_, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
     LAVIE_HIP(hipMemcpy(buckets_dev_, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice));
-    for (size_t i = 0; i < transformers_.size(); ++i) {
-        WALLOC(relbias_[i], float, (size_t)cfg_.heads * F * F);
-        RUN(launch_fill_relpos_bias(transformers_[i].relemb, buckets_dev_, relbias_[i], cfg_.heads, F, s));
+    if (cfg_.temporal_plain) {
+        // plain softmax(scale q k^T) v over frames (interpolation/models/attention.py:268-289): one shared all-zero bias
+        // table (s + 0.0f == s exactly) and rot_dim = 0 in the kernel parameters
+        float* zero = nullptr;
+        WALLOC(zero, float, (size_t)cfg_.heads * F * F);
+        LAVIE_HIP(hipMemsetAsync(zero, 0, (size_t)cfg_.heads * F * F * sizeof(float), s));
+        for (size_t i = 0; i < transformers_.size(); ++i) relbias_[i] = zero;
+    } else {
+        for (size_t i = 0; i < transformers_.size(); ++i) {
+            WALLOC(relbias_[i], float, (size_t)cfg_.heads * F * F);
+            RUN(launch_fill_relpos_bias(transformers_[i].relemb, buckets_dev_, relbias_[i], cfg_.heads, F, s));
+        }
     }
     LAVIE_HIP(hipStreamSynchronize(s));
     tables_F_ = F;
@@ -617,6 +630,10 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         AttnParams a;
         a.q = wide; a.ldq = 3 * C; a.k = wide + C; a.ldk = 3 * C; a.v = wide + 2 * C; a.ldv = 3 * C;
         a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = D; a.heads = heads; a.dh = dh; a.kv_batch_div = 1; a.scale = scale;
+        if (cfg_.sparse_causal_attn1) {      // keys/values = first frame || previous frame (interpolation attention.py:630-639)
+            a.Lk = 2 * D;
+            a.sc_frames = c.F;
+        }
         RUN(launch_attention(a, c.s));
     }
     RUN(linear(c, att, C, t.o1.w, t.o1.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
@@ -638,31 +655,52 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     }
     RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
 
-    // temporal self-attention over frames, tokens stay in (b f) d order (attention.py:548-555)
-    if (fold) {
-        lf.s = t.s_qkvt;
-        RUN(linear(c, tx, C, t.f_qkvt, t.b_qkvt, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
+    // base block order: temporal -> feed-forward (attention.py:548-560); interpolation block: feed-forward -> temporal
+    // (interpolation/models/attention.py:592-604)
+    const bool ff_first = cfg_.ff_before_temporal != 0;
+    RowStat rsd_ff2 = rsd;
+    rsd_ff2.slots = C / igemm_rowstat_cols(T, C, 4 * C / IGEMM_BK);
+    const RowStat* rowstat_ff2 = rowstat ? &rsd_ff2 : nullptr;
+    auto temporal = [&]() -> int {
+        // temporal self-attention over frames, tokens stay in (b f) d order (attention.py:548-555)
+        if (fold) {
+            lf.s = t.s_qkvt;
+            RUN(linear(c, tx, C, t.f_qkvt, t.b_qkvt, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
+        } else {
+            LAUNCH(launch_layernorm(tx, t.lnt.g, t.lnt.b, ln, T, C, 1e-5f, c.s));
+            RUN(linear(c, ln, C, t.wqkvt, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+        }
+        if (!c.dry) {
+            TemporalParams tp;
+            tp.qkv = wide; tp.ld = 3 * C; tp.o = att; tp.ldo = C; tp.B = c.B; tp.F = c.F; tp.D = D; tp.heads = heads; tp.dh = dh;
+            tp.bias = relbias_[ti]; tp.rot_cos = rot_cos_; tp.rot_sin = rot_sin_; tp.rot_dim = cfg_.temporal_plain ? 0 : cfg_.rotary_dim; tp.scale = scale;
+            RUN(launch_temporal_attention(tp, c.s));
+        }
+        // its output feeds norm3 only in the base order; in the interpolation order proj_out follows (no LayerNorm)
+        RUN(linear(c, att, C, t.ot.w, t.ot.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, ff_first ? nullptr : rowstat));
+        return 0;
+    };
+    auto feed_forward = [&]() -> int {
+        // GEGLU feed-forward (attention.py:558)
+        if (fold) {
+            lf.s = t.s_ff1;
+            RUN(linear(c, tx, C, t.f_ff1, t.b_ff1, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU, &lf));
+        } else {
+            LAUNCH(launch_layernorm(tx, t.ln3.g, t.ln3.b, ln, T, C, 1e-5f, c.s));
+            RUN(linear(c, ln, C, t.ff1.w, t.ff1.b, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU));
+        }
+        // interpolation order: norm_temp consumes this GEMM's output, so it emits the row statistics (K = 4C: the
+        // planner may pick another kernel than for the K = C producers, hence its own slot count)
+        RUN(linear(c, wide, 4 * C, t.ff2.w, t.ff2.b, C, 4 * C, tx, tx, C, T, EPI_LINEAR, nullptr, ff_first ? rowstat_ff2 : nullptr));
+        return 0;
+    };
+    if (ff_first) {
+        RUN(feed_forward());
+        RUN(temporal());
     } else {
-        LAUNCH(launch_layernorm(tx, t.lnt.g, t.lnt.b, ln, T, C, 1e-5f, c.s));
-        RUN(linear(c, ln, C, t.wqkvt, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+        RUN(temporal());
+        RUN(feed_forward());
     }
-    if (!c.dry) {
-        TemporalParams tp;
-        tp.qkv = wide; tp.ld = 3 * C; tp.o = att; tp.ldo = C; tp.B = c.B; tp.F = c.F; tp.D = D; tp.heads = heads; tp.dh = dh;
-        tp.bias = relbias_[ti]; tp.rot_cos = rot_cos_; tp.rot_sin = rot_sin_; tp.rot_dim = cfg_.rotary_dim; tp.scale = scale;
-        RUN(launch_temporal_attention(tp, c.s));
-    }
-    RUN(linear(c, att, C, t.ot.w, t.ot.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
-
-    // GEGLU feed-forward (attention.py:558)
-    if (fold) {
-        lf.s = t.s_ff1;
-        RUN(linear(c, tx, C, t.f_ff1, t.b_ff1, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU, &lf));
-    } else {
-        LAUNCH(launch_layernorm(tx, t.ln3.g, t.ln3.b, ln, T, C, 1e-5f, c.s));
-        RUN(linear(c, ln, C, t.ff1.w, t.ff1.b, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU));
-    }
-    RUN(linear(c, wide, 4 * C, t.ff2.w, t.ff2.b, C, 4 * C, tx, tx, C, T));
 
     // 1x1 proj_out + residual, in place on the block input (attention.py:394-401)
     RUN(linear(c, tx, C, t.pout.w, t.pout.b, C, C, x, x, C, T));

@@ -25,6 +25,9 @@ struct AttnParams {
     int NBq, Lq, Lk, heads, dh;
     int kv_batch_div;                // kv batch index = q batch index / kv_batch_div (text ctx shared by the frames)
     float scale;
+    // sparse-causal self-attention (interpolation/models/attention.py:609-665): sc_frames > 0 => batch entry (b, f) reads
+    // keys [0, Lk/2) from frame (b, 0) and keys [Lk/2, Lk) from frame (b, max(f-1, 0)); Lk = 2 * Lq, kv_batch_div = 1
+    int sc_frames = 0;
 };
 int launch_attention(const AttnParams& p, hipStream_t stream);
 void attention_force_qt(int qt);   // tuning knob: query tiles per wave for head dims <= 64 (0 = automatic)

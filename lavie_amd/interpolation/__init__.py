@@ -1,0 +1,3 @@
+"""Host-side mirror of the reference's frame-interpolation stage (`interpolation/`): the 16 -> 61 frame
+UNet variant on the same gfx950 engine."""
+from .unet import UNet3DConditionModel  # noqa: F401

@@ -150,6 +150,22 @@ def attention(q, k, v, nb, lq, lk, heads, kv_batch_div=1, scale=None):
     return o
 
 
+def sparse_causal_attention(q, k, v, nb, frames, d, heads, scale=None):
+    """SparseCausalAttention core (interpolation/models/attention.py:609-665): q/k/v [nb*d, *] per-frame rows (column
+    slices of a wider tensor allowed); frame f of a video attends to [first frame || frame max(f-1, 0)] of that video."""
+    for t in (q, k, v):
+        if not (t.is_cuda and t.dtype == torch.float16 and t.stride(1) == 1):
+            raise ValueError("attention operands must be fp16 device tensors with unit column stride")
+    c = q.shape[1]
+    dh = c // heads
+    o = torch.empty(nb * d, c, dtype=torch.float16, device=q.device)
+    scale = dh ** -0.5 if scale is None else scale
+    _lib.check(_lib.load().lavie_sparse_causal_attention_f16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0),
+                                                             _p(o), c, nb, frames, d, heads, dh, float(scale), _stream()),
+               "lavie_sparse_causal_attention_f16")
+    return o
+
+
 def relpos_buckets(frames: int, num_buckets: int = 32, max_distance: int = 32) -> torch.Tensor:
     """Host-side bucket table [F, F] (query i, key j) — needs no GPU."""
     buf = (ctypes.c_int * (frames * frames))()
@@ -167,7 +183,7 @@ def rotary_tables(frames: int, rot_dim: int = 32, theta: float = 10000.0, device
 def temporal_attention(qkv, b, frames, d, heads, bias, rot_cos, rot_sin, rot_dim=32, scale=None):
     """qkv [(b f d), 3C] (q | k | v) in (b, f, pixel) token order -> [(b f d), C]."""
     _chk16(qkv)
-    _chk32(bias, rot_cos, rot_sin)
+    _chk32(bias, *(() if rot_dim == 0 else (rot_cos, rot_sin)))      # rot_dim = 0: no rotary embedding, tables may be None
     c = qkv.shape[1] // 3
     dh = c // heads
     o = torch.empty(qkv.shape[0], c, dtype=torch.float16, device=qkv.device)

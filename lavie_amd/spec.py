@@ -53,8 +53,9 @@ def _transformer(prefix: str, c: int, cfg: UNetConfig) -> Iterator[Tuple[str, Sh
     yield from _attention(blk + ".attn2", c, cfg.cross_attention_dim)
     yield from _affine(blk + ".norm2", c)
     yield from _attention(blk + ".attn_temp", c, c)
-    yield blk + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight", (cfg.rel_buckets, cfg.heads)
-    yield blk + ".attn_temp.rotary_emb.freqs", (cfg.rotary_dim // 2,)
+    if not cfg.temporal_plain:
+        yield blk + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight", (cfg.rel_buckets, cfg.heads)
+        yield blk + ".attn_temp.rotary_emb.freqs", (cfg.rotary_dim // 2,)
     yield from _affine(blk + ".norm_temp", c)
     yield from _linear(blk + ".ff.net.0.proj", c, 8 * c)
     yield from _linear(blk + ".ff.net.2", 4 * c, c)

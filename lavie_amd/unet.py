@@ -39,6 +39,9 @@ def _attach(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
 
 class UNet3DConditionModel(nn.Module):
     _supported_down = ("CrossAttnDownBlock3D", "DownBlock3D")
+    # transformer-block variant (UNetConfig fields); lavie_amd.interpolation.unet overrides it
+    _block_variant = dict(sparse_causal_attn1=False, temporal_plain=False, ff_before_temporal=False)
+    _allow_first_frame = False
 
     def __init__(
         self,
@@ -79,7 +82,7 @@ class UNet3DConditionModel(nn.Module):
             "center_input_sample": center_input_sample, "only_cross_attention": only_cross_attention,
             "dual_cross_attention": dual_cross_attention, "use_linear_projection": use_linear_projection,
             "class_embed_type": class_embed_type, "num_class_embeds": num_class_embeds,
-            "upcast_attention": upcast_attention, "use_first_frame": use_first_frame,
+            "upcast_attention": upcast_attention, "use_first_frame": use_first_frame and not self._allow_first_frame,
             "use_relative_position": use_relative_position,
         }
         bad = [k for k, v in unsupported.items() if v]
@@ -101,7 +104,8 @@ class UNet3DConditionModel(nn.Module):
         self.cfg = UNetConfig(sample_size=sample_size or 64, in_channels=in_channels, out_channels=out_channels,
                               block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
                               heads=attention_head_dim, cross_attention_dim=cross_attention_dim,
-                              norm_groups=norm_num_groups, norm_eps=norm_eps, attn_levels=attn)
+                              norm_groups=norm_num_groups, norm_eps=norm_eps, attn_levels=attn,
+                              **dict(self._block_variant, sparse_causal_attn1=bool(use_first_frame) and self._allow_first_frame))
         self.cfg.validate()
         self.config = SimpleNamespace(
             sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
@@ -183,6 +187,8 @@ class UNet3DConditionModel(nn.Module):
         c.layers_per_block, c.heads = cfg.layers_per_block, cfg.heads
         c.cross_attention_dim, c.norm_groups, c.norm_eps = cfg.cross_attention_dim, cfg.norm_groups, cfg.norm_eps
         c.rotary_dim, c.rel_buckets, c.rel_max_distance = cfg.rotary_dim, cfg.rel_buckets, cfg.rel_max_distance
+        c.sparse_causal_attn1, c.temporal_plain = int(cfg.sparse_causal_attn1), int(cfg.temporal_plain)
+        c.ff_before_temporal = int(cfg.ff_before_temporal)
         return c
 
     def _ensure_engine(self):

@@ -35,9 +35,16 @@ class UNetConfig:
     rel_max_distance: int = 32
     # which levels carry transformer blocks: CrossAttnDownBlock3D x3 + DownBlock3D (unet.py:110-122)
     attn_levels: Tuple[bool, ...] = field(default=(True, True, True, False))
+    # --- the frame-interpolation model's block variant (interpolation/models/attention.py:456-606) ---
+    sparse_causal_attn1: bool = False   # `use_first_frame`: attn1 keys/values = first frame || previous frame (:609-665)
+    temporal_plain: bool = False        # attn_temp is a plain CrossAttention over frames: no rotary, no bias (:525-533, 211-289)
+    ff_before_temporal: bool = False    # block order spatial -> text -> FF -> temporal (:566-606)
 
 
 BASE = UNetConfig()
+# UNet3DConditionModel.from_pretrained_2d(..., use_concat=True, copy_no_mask=True) (interpolation/models/unet.py:477-506):
+# 8 input channels (noisy latent || copied low-frame-rate latent), use_first_frame=True, use_relative_position=False
+INTERPOLATION = UNetConfig(in_channels=8, sparse_causal_attn1=True, temporal_plain=True, ff_before_temporal=True)
 
 
 # --------------------------------------------------------------------------- embeddings
@@ -118,6 +125,23 @@ def cross_attention(sd: SD, p: str, x, ctx, heads):
     return F.linear(merge_heads(prob @ v), sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
 
 
+def sparse_causal_attention(sd: SD, p: str, x, frames: int, heads: int):
+    """SparseCausalAttention.forward (interpolation/models/attention.py:609-665): x [(b f), d, c]; frame i attends to the
+    2d keys/values [frame 0 of its video || frame max(i-1, 0)] (:630-639), plain softmax(scale q k^T) v (:268-289)."""
+    bf, d, c = x.shape
+    q = split_heads(F.linear(x, sd[p + "to_q.weight"]), heads)
+    former = (torch.arange(frames) - 1).clamp(min=0)
+
+    def gather(t):
+        t = t.reshape(bf // frames, frames, d, c)
+        return torch.cat([t[:, [0] * frames], t[:, former]], dim=2).reshape(bf, 2 * d, c)
+
+    k = split_heads(gather(F.linear(x, sd[p + "to_k.weight"])), heads)
+    v = split_heads(gather(F.linear(x, sd[p + "to_v.weight"])), heads)
+    prob = torch.softmax((q.shape[-1] ** -0.5) * (q @ k.transpose(-1, -2)), dim=-1)
+    return F.linear(merge_heads(prob @ v), sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+
+
 def rel_pos_bucket_table(n: int, num_buckets: int = 32, max_distance: int = 32) -> torch.Tensor:
     """RelativePositionBias._relative_position_bucket on rel = k_pos - q_pos
     (attention.py:681-705).  Entry [i, j] is the bucket for query i, key j (int64)."""
@@ -191,13 +215,27 @@ def layer_norm(sd: SD, p: str, x):
 
 def transformer_block(sd: SD, p: str, x, ctx, frames: int, cfg: UNetConfig):
     """BasicTransformerBlock.forward, eval branch (attention.py:511-534, 548-560).
-    x: [(b f), d, c]; ctx: [(b f), 77, cross_dim].  Order: spatial -> text -> temporal -> FF."""
-    x = x + cross_attention(sd, p + "attn1.", layer_norm(sd, p + "norm1.", x), None, cfg.heads)
+    x: [(b f), d, c]; ctx: [(b f), 77, cross_dim].  Order: spatial -> text -> temporal -> FF.
+    Interpolation variant (interpolation/models/attention.py:566-606): sparse-causal attn1, order spatial -> text -> FF ->
+    temporal, and attn_temp is the plain CrossAttention (no rotary, no relative-position bias)."""
+    n1 = layer_norm(sd, p + "norm1.", x)
+    if cfg.sparse_causal_attn1:
+        x = x + sparse_causal_attention(sd, p + "attn1.", n1, frames, cfg.heads)
+    else:
+        x = x + cross_attention(sd, p + "attn1.", n1, None, cfg.heads)
     x = x + cross_attention(sd, p + "attn2.", layer_norm(sd, p + "norm2.", x), ctx, cfg.heads)
+    if cfg.ff_before_temporal:
+        x = x + geglu_ff(sd, p + "ff.", layer_norm(sd, p + "norm3.", x))
     bf, d, c = x.shape
     xt = x.reshape(bf // frames, frames, d, c).permute(0, 2, 1, 3).reshape(-1, frames, c)      # (b d) f c
-    xt = xt + temporal_attention(sd, p + "attn_temp.", layer_norm(sd, p + "norm_temp.", xt), cfg)
+    nt = layer_norm(sd, p + "norm_temp.", xt)
+    if cfg.temporal_plain:
+        xt = xt + cross_attention(sd, p + "attn_temp.", nt, None, cfg.heads)
+    else:
+        xt = xt + temporal_attention(sd, p + "attn_temp.", nt, cfg)
     x = xt.reshape(bf // frames, d, frames, c).permute(0, 2, 1, 3).reshape(bf, d, c)
+    if cfg.ff_before_temporal:
+        return x
     return x + geglu_ff(sd, p + "ff.", layer_norm(sd, p + "norm3.", x))
 
 
@@ -304,8 +342,9 @@ def param_shapes(cfg: UNetConfig = BASE) -> Dict[str, Tuple[int, ...]]:
         attn(b + "attn2.", c, ctxd)
         norm(b + "norm2.", c)
         attn(b + "attn_temp.", c, c)
-        out[b + "attn_temp.time_rel_pos_bias.relative_attention_bias.weight"] = (cfg.rel_buckets, cfg.heads)
-        out[b + "attn_temp.rotary_emb.freqs"] = (cfg.rotary_dim // 2,)
+        if not cfg.temporal_plain:
+            out[b + "attn_temp.time_rel_pos_bias.relative_attention_bias.weight"] = (cfg.rel_buckets, cfg.heads)
+            out[b + "attn_temp.rotary_emb.freqs"] = (cfg.rotary_dim // 2,)
         norm(b + "norm_temp.", c)
         lin(b + "ff.net.0.proj.", c, 8 * c)
         lin(b + "ff.net.2.", 4 * c, c)

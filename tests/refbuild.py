@@ -34,3 +34,18 @@ def reference_unet(cfg: UNetConfig, seed: int):
     missing, unexpected = net.load_state_dict(sd, strict=True), None
     net.eval()
     return net, sd
+
+
+def reference_interpolation_unet(cfg: UNetConfig, seed: int):
+    """interpolation/models/unet.py's UNet3DConditionModel as `from_pretrained_2d(use_concat, copy_no_mask)` configures
+    it (in_channels 8, use_first_frame=True), weights left uninitialised for the caller to load."""
+    m = refimport.load("interpolation")
+    with _no_init():
+        net = m.unet.UNet3DConditionModel(
+            sample_size=cfg.sample_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+            block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+            cross_attention_dim=cfg.cross_attention_dim, attention_head_dim=cfg.heads,
+            norm_num_groups=cfg.norm_groups, norm_eps=cfg.norm_eps, use_first_frame=cfg.sparse_causal_attn1,
+            down_block_types=tuple("CrossAttnDownBlock3D" if a else "DownBlock3D" for a in cfg.attn_levels),
+            up_block_types=tuple("CrossAttnUpBlock3D" if a else "UpBlock3D" for a in reversed(cfg.attn_levels)))
+    return net.eval()

@@ -14,19 +14,22 @@ def available():
     return os.path.isfile(os.path.join(REF, "unet.py"))
 
 
-def load():
-    """Returns the reference modules (resnet, attention, unet_blocks, unet) as a namespace."""
-    if "refmodels.unet" in sys.modules:
-        return sys.modules["refmodels"]
+def load(stage="base"):
+    """Returns the reference modules (resnet, attention, unet_blocks, unet) of `<stage>/models` as a namespace;
+    stage is "base" (the T2V denoiser) or "interpolation" (the 16 -> 61 frame model)."""
+    pkgname = "refmodels" if stage == "base" else f"refmodels_{stage}"
+    if f"{pkgname}.unet" in sys.modules:
+        return sys.modules[pkgname]
     if _SHIM not in sys.path:
         sys.path.insert(0, _SHIM)
-    pkg = importlib.util.module_from_spec(importlib.machinery.ModuleSpec("refmodels", None, is_package=True))
-    pkg.__path__ = [REF]
-    sys.modules["refmodels"] = pkg
+    root = REF if stage == "base" else f"/root/reference/{stage}/models"
+    pkg = importlib.util.module_from_spec(importlib.machinery.ModuleSpec(pkgname, None, is_package=True))
+    pkg.__path__ = [root]
+    sys.modules[pkgname] = pkg
     for name in ("resnet", "attention", "unet_blocks", "unet"):
-        spec = importlib.util.spec_from_file_location(f"refmodels.{name}", os.path.join(REF, f"{name}.py"))
+        spec = importlib.util.spec_from_file_location(f"{pkgname}.{name}", os.path.join(root, f"{name}.py"))
         mod = importlib.util.module_from_spec(spec)
-        sys.modules[f"refmodels.{name}"] = mod
+        sys.modules[f"{pkgname}.{name}"] = mod
         spec.loader.exec_module(mod)
         setattr(pkg, name, mod)
     return pkg

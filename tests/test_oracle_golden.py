@@ -91,3 +91,28 @@ def test_ddim_steps_match_reference_fixture():
     for t in ch["timesteps"]:
         x = sch.step(torch.tanh(x * 0.7 + 0.01 * t / 1000.0), t, x)
     assert rel_l2(x, ch["y"]) < 1e-6
+
+
+# ------------------------------------------------------------------ frame-interpolation model
+def test_interp_sparse_causal_attention():
+    for c in G.load("interp_sparse_causal.pt")["cases"]:
+        sd = G.synth16(c["shapes"], c["seed"], "a.")
+        got = O.sparse_causal_attention(sd, "a.", c["x"].float(), c["frames"], 8)
+        assert rel_l2(got, c["y"]) < 1e-3          # fixture outputs are stored in fp16
+
+
+def test_interp_transformer3d():
+    for c in G.load("interp_transformer3d.pt")["cases"]:
+        sd = G.synth16(c["shapes"], c["seed"], "t.")
+        got = O.transformer3d(sd, "t.", c["x"].float(), c["ctx"].float(), O.INTERPOLATION)
+        assert rel_l2(got, c["y"]) < 1e-5, c["frames"]
+
+
+def test_interp_whole_unet_full_width():
+    from lavie_amd.config import INTERPOLATION_CONFIG
+    fx = G.load("interp_unet_full_8x8.pt")
+    sd = G.synth16(spec.param_shapes(INTERPOLATION_CONFIG), fx["seed"])
+    assert O.param_shapes(O.INTERPOLATION) == spec.param_shapes(INTERPOLATION_CONFIG)
+    for t, ref in fx["y"].items():
+        got = O.unet_forward(sd, fx["x"].float(), int(t), fx["ctx"].float(), O.INTERPOLATION)
+        assert rel_l2(got, ref) < 1e-4, t

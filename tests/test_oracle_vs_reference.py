@@ -4,7 +4,7 @@ import torch
 
 import refbuild
 import refimport
-from lavie_amd import spec
+from lavie_amd import spec, weights
 from lavie_amd.config import UNetConfig
 from oracle import unet_fp32 as O
 
@@ -138,3 +138,25 @@ def test_ddim_oracle_matches_vendored_reference_scheduler():
         for eta in (0.0, 1.0):
             want = ref.step(eps, t, x, eta=eta, variance_noise=z if eta > 0 else None).prev_sample
             assert rel_l2(sch.step(eps, t, x, eta=eta, noise=z), want) < 1e-6
+
+
+# ------------------------------------------------------------------ frame-interpolation model
+def test_interpolation_unet_small_matches_reference():
+    """oracle (sparse-causal attn1, FF before temporal, plain temporal attention, 8 input channels) against the imported
+    interpolation/models UNet at a small width, ragged frame count; also pins the state-dict contract."""
+    m = refimport.load("interpolation")
+    cfg = O.UNetConfig(in_channels=8, block_out_channels=(64, 128), attn_levels=(True, False), layers_per_block=1,
+                       cross_attention_dim=64, sparse_causal_attn1=True, temporal_plain=True, ff_before_temporal=True)
+    net = m.unet.UNet3DConditionModel(sample_size=8, in_channels=8, out_channels=4, block_out_channels=(64, 128),
+                                      down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"),
+                                      up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"), layers_per_block=1,
+                                      cross_attention_dim=64, attention_head_dim=8, use_first_frame=True).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert shapes == O.param_shapes(cfg)
+    sd = weights.synth_state_dict(shapes, 8)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    x, ctx = torch.randn(2, 8, 7, 8, 8, generator=g), torch.randn(2, 77, 64, generator=g)
+    with torch.no_grad():
+        ref = net(x, torch.tensor(500), encoder_hidden_states=ctx).sample
+    assert rel_l2(O.unet_forward(sd, x, 500, ctx, cfg), ref) < 1e-5
