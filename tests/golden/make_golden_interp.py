@@ -65,6 +65,25 @@ def main():
     cfg_out = net.forward_with_cfg(x, torch.tensor([500, 500]), encoder_hidden_states=ctx, cfg_scale=4.0)
     save("interp_unet_full_8x8.pt", dict(seed=seed, x=x.half(), ctx=ctx.half(), y=outs, y_cfg=cfg_out))
 
+    # (4) the sampler: create_diffusion's respaced schedule tables and a whole 4-step ddim_sample_loop driven exactly as
+    #     interpolation/sample.py:138-174 does (forward_with_cfg, x_start = copied low-frame-rate latent, use_concat,
+    #     copy_no_mask, clip_denoised=False), with the reference UNet from (3) as the denoiser
+    rd = refimport.load_interp_diffusion()
+    tables = {}
+    for n in ("50", "4"):
+        d = rd.create_diffusion(n)
+        tables[n] = dict(timestep_map=torch.tensor(d.timestep_map), alphas_cumprod=torch.from_numpy(d.alphas_cumprod),
+                         alphas_cumprod_prev=torch.from_numpy(d.alphas_cumprod_prev))
+    z = q16(torch.randn(1, 4, 5, 8, 8, generator=g))
+    xs = q16(torch.randn(1, 4, 5, 8, 8, generator=g))
+    ctx2 = q16(torch.randn(2, 77, 768, generator=g))          # [prompt, negative] (sample.py:157)
+    z2, xs2 = torch.cat([z] * 2), torch.cat([xs] * 2)
+    d = rd.create_diffusion("4")
+    out = d.ddim_sample_loop(net.forward_with_cfg, z2.shape, z2, clip_denoised=False,
+                             model_kwargs=dict(encoder_hidden_states=ctx2, class_labels=None), progress=False, device="cpu",
+                             mask=None, x_start=xs2, use_concat=True, copy_no_mask=True)
+    save("interp_ddim.pt", dict(seed=seed, tables=tables, z=z, x_start=xs, ctx=ctx2.half(), steps="4", y=out))
+
 
 if __name__ == "__main__":
     main()

@@ -46,3 +46,16 @@ def load_vsr_ddim():
     sys.modules["ref_vsr_ddim"] = mod
     spec.loader.exec_module(mod)
     return mod.DDIMScheduler
+
+
+def load_interp_diffusion():
+    """The reference's in-tree OpenAI-style diffusion package (interpolation/diffusion: numpy + torch only)."""
+    name = "ref_interp_diffusion"
+    if name in sys.modules:
+        return sys.modules[name]
+    root = "/root/reference/interpolation/diffusion"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(root, "__init__.py"), submodule_search_locations=[root])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod

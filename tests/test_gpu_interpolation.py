@@ -149,3 +149,29 @@ def test_interp_without_first_frame_is_plain_attn1(small):
     ref = O.unet_forward(sd, x.float(), 250, ctx.float(), ocfg_small(sparse_causal_attn1=False))
     got = net(x.cuda(), 250, encoder_hidden_states=ctx.cuda()).sample
     assert rel_l2(got, ref) < TOL_UNET
+
+
+def test_interp_ddim_loop_golden(full):
+    """create_diffusion("4").ddim_sample_loop(model.forward_with_cfg, ...) through the engine + fused guidance/update
+    kernel, against the loop the reference's interpolation/diffusion package ran with the reference UNet."""
+    from lavie_amd.interpolation import create_diffusion
+    net, _, _ = full
+    fx = G.load("interp_ddim.pt")
+    z2, xs2 = torch.cat([fx["z"]] * 2).cuda(), torch.cat([fx["x_start"]] * 2).cuda()
+    out = create_diffusion(fx["steps"]).ddim_sample_loop(
+        net.forward_with_cfg, z2.shape, z2, clip_denoised=False,
+        model_kwargs=dict(encoder_hidden_states=fx["ctx"].cuda(), class_labels=None), progress=False, device="cuda",
+        mask=None, x_start=xs2, use_concat=True, copy_no_mask=True)
+    assert out.shape == fx["y"].shape and torch.equal(out[0], out[1])
+    assert rel_l2(out, fx["y"]) < 2e-2          # four chained fp16 UNet forwards under guidance 4.0
+
+
+def test_interp_ddim_loop_rejects_unsupported_modes(full):
+    from lavie_amd.interpolation import create_diffusion
+    net, _, _ = full
+    d = create_diffusion("4")
+    z = torch.zeros(2, 4, 2, 8, 8, device="cuda")
+    with pytest.raises(NotImplementedError):
+        d.ddim_sample_loop(net.forward_with_cfg, z.shape, z, clip_denoised=True)
+    with pytest.raises(NotImplementedError):
+        d.ddim_sample_loop(net.forward_with_cfg, z.shape, z, clip_denoised=False, mask=z)

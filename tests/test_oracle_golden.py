@@ -116,3 +116,21 @@ def test_interp_whole_unet_full_width():
     for t, ref in fx["y"].items():
         got = O.unet_forward(sd, fx["x"].float(), int(t), fx["ctx"].float(), O.INTERPOLATION)
         assert rel_l2(got, ref) < 1e-4, t
+
+
+def test_interp_ddim_schedule_and_loop():
+    """oracle/interp_ddim.py against the fixture the reference's interpolation/diffusion package + UNet produced."""
+    from lavie_amd.config import INTERPOLATION_CONFIG
+    from oracle import interp_ddim as D
+    fx = G.load("interp_ddim.pt")
+    for n, tab in fx["tables"].items():
+        s = D.SpacedSchedule(n)
+        assert s.timestep_map == tab["timestep_map"].tolist()
+        assert torch.equal(torch.from_numpy(s.alphas_cumprod), tab["alphas_cumprod"])
+        assert torch.equal(torch.from_numpy(s.alphas_cumprod_prev), tab["alphas_cumprod_prev"])
+    sd = G.synth16(spec.param_shapes(INTERPOLATION_CONFIG), fx["seed"])
+    unet = lambda x, t, c: O.unet_forward(sd, x, t, c, O.INTERPOLATION)
+    z2, xs2 = torch.cat([fx["z"]] * 2), torch.cat([fx["x_start"]] * 2)
+    got = D.ddim_sample_loop(unet, z2, xs2, fx["ctx"].float(), D.SpacedSchedule(fx["steps"]), 4.0)
+    assert rel_l2(got, fx["y"]) < 1e-4
+    assert torch.equal(got[0], got[1])

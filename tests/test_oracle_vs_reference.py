@@ -160,3 +160,32 @@ def test_interpolation_unet_small_matches_reference():
     with torch.no_grad():
         ref = net(x, torch.tensor(500), encoder_hidden_states=ctx).sample
     assert rel_l2(O.unet_forward(sd, x, 500, ctx, cfg), ref) < 1e-5
+
+
+def test_interpolation_ddim_loop_matches_reference_diffusion():
+    """oracle/interp_ddim.py and the product's host-side SpacedDiffusion (generic loop) against the reference's
+    interpolation/diffusion package, driven as interpolation/sample.py:160-168 does, with a small linear denoiser."""
+    import numpy as np
+    from lavie_amd.interpolation import create_diffusion
+    from oracle import interp_ddim as D
+    rd = refimport.load_interp_diffusion()
+    for n in ("50", "25", "7"):
+        r, s, p = rd.create_diffusion(n), D.SpacedSchedule(n), create_diffusion(n)
+        assert r.timestep_map == s.timestep_map == p.timestep_map
+        assert np.array_equal(r.alphas_cumprod, s.alphas_cumprod) and np.array_equal(r.alphas_cumprod, p.alphas_cumprod)
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(4, 8, generator=g) * 0.05
+    toy = lambda x, t, c: (torch.einsum("oc,bcfhw->bofhw", W, x) * (1 + t.float().reshape(-1, 1, 1, 1, 1) / 1000)
+                           + 0.1 * c.mean(dim=(1, 2)).reshape(-1, 1, 1, 1, 1))
+
+    def fwd_cfg(x, t, encoder_hidden_states=None, class_labels=None, cfg_scale=4.0):
+        return D.forward_with_cfg(toy, x, t, encoder_hidden_states, cfg_scale)
+
+    z = torch.cat([torch.randn(1, 4, 3, 4, 4, generator=g)] * 2)
+    xs = torch.cat([torch.randn(1, 4, 3, 4, 4, generator=g)] * 2)
+    ctx = torch.randn(2, 7, 5, generator=g)
+    kw = dict(clip_denoised=False, model_kwargs=dict(encoder_hidden_states=ctx, class_labels=None), mask=None, x_start=xs,
+              use_concat=True, copy_no_mask=True)
+    ref = rd.create_diffusion("10").ddim_sample_loop(fwd_cfg, z.shape, z, progress=False, device="cpu", **kw)
+    assert rel_l2(D.ddim_sample_loop(toy, z, xs, ctx, D.SpacedSchedule("10"), 4.0), ref) < 1e-6
+    assert rel_l2(create_diffusion("10").ddim_sample_loop(fwd_cfg, z.shape, z, **kw), ref) < 1e-6
