@@ -111,6 +111,12 @@ int lavie_relpos_buckets(int F, int num_buckets, int max_distance, int* out_host
 int lavie_cfg_ddpm_step(const void* eps2, float* x, const float* noise, void* model_in2, long long n, float guidance,
                         float k_x, float k_eps, float c_x0, float c_xt, float sigma, void* stream);
 int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, void* stream);
+/* Same two kernels for schedulers whose `scale_model_input` is not the identity (EulerDiscreteScheduler, sample_method
+ * 'eulerdiscrete', base/pipelines/sample.py:50-55; pipeline_videogen.py:667): the fp16 model input written for the NEXT
+ * UNet call is x' * next_input_scale (Euler: 1 / sqrt(sigma_next^2 + 1)); x itself stays unscaled in fp32. */
+int lavie_cfg_sampler_step(const void* eps2, float* x, const float* noise, void* model_in2, long long n, float guidance,
+                           float k_x, float k_eps, float c_x0, float c_xt, float sigma, float next_input_scale, void* stream);
+int lavie_latents_to_scaled_model_input(const float* x, void* model_in2, long long n, float input_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hook: HIP-event timing per kernel class on the launch stream (bench.py's roofline leg).

@@ -49,6 +49,9 @@ SIGNATURES = {
     "lavie_cfg_ddpm_step": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
                                      c_float, c_float, c_void_p]),
     "lavie_latents_to_model_input": (c_int, [c_float_p, c_void_p, c_ll, c_void_p]),
+    "lavie_cfg_sampler_step": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
+                                        c_float, c_float, c_float, c_void_p]),
+    "lavie_latents_to_scaled_model_input": (c_int, [c_float_p, c_void_p, c_ll, c_float, c_void_p]),
     "lavie_debug_force_tile": (c_int, [c_int]),
     "lavie_debug_force_splits": (c_int, [c_int]),
     "lavie_debug_conv_tap_major": (c_int, [c_int]),

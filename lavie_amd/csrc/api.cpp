@@ -164,12 +164,24 @@ int lavie_relpos_buckets(int F, int num_buckets, int max_distance, int* out_host
 int lavie_cfg_ddpm_step(const void* eps2, float* x, const float* noise, void* model_in2, long long n, float guidance,
                         float k_x, float k_eps, float c_x0, float c_xt, float sigma, void* stream) {
     LAVIE_CHECK(eps2 && x && model_in2 && n > 0, "cfg_ddpm_step: bad arguments");
-    return launch_cfg_ddpm_step(H(eps2), x, noise, H(model_in2), n, guidance, k_x, k_eps, c_x0, c_xt, sigma, S(stream));
+    return launch_cfg_ddpm_step(H(eps2), x, noise, H(model_in2), n, guidance, k_x, k_eps, c_x0, c_xt, sigma, 1.0f, S(stream));
+}
+
+int lavie_cfg_sampler_step(const void* eps2, float* x, const float* noise, void* model_in2, long long n, float guidance,
+                           float k_x, float k_eps, float c_x0, float c_xt, float sigma, float next_input_scale, void* stream) {
+    LAVIE_CHECK(eps2 && x && model_in2 && n > 0, "cfg_sampler_step: bad arguments");
+    return launch_cfg_ddpm_step(H(eps2), x, noise, H(model_in2), n, guidance, k_x, k_eps, c_x0, c_xt, sigma, next_input_scale,
+                                S(stream));
 }
 
 int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, void* stream) {
     LAVIE_CHECK(x && model_in2 && n > 0, "latents_to_model_input: bad arguments");
-    return launch_f32_to_f16_dup2(x, H(model_in2), n, S(stream));
+    return launch_f32_to_f16_dup2(x, H(model_in2), n, 1.0f, S(stream));
+}
+
+int lavie_latents_to_scaled_model_input(const float* x, void* model_in2, long long n, float input_scale, void* stream) {
+    LAVIE_CHECK(x && model_in2 && n > 0, "latents_to_scaled_model_input: bad arguments");
+    return launch_f32_to_f16_dup2(x, H(model_in2), n, input_scale, S(stream));
 }
 
 int lavie_debug_force_tile(int mode) { igemm_force_tile(mode); return 0; }

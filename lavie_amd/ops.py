@@ -194,21 +194,23 @@ def temporal_attention(qkv, b, frames, d, heads, bias, rot_cos, rot_sin, rot_dim
     return o
 
 
-def cfg_ddpm_step(eps2, x, noise, model_in2, guidance, coeffs):
-    """Fused CFG + DDPM update; `coeffs` = (k_x, k_eps, c_x0, c_xt, sigma) from DDPMScheduler.coefficients."""
+def cfg_ddpm_step(eps2, x, noise, model_in2, guidance, coeffs, next_input_scale: float = 1.0):
+    """Fused CFG + scheduler update; `coeffs` = (k_x, k_eps, c_x0, c_xt, sigma) from <scheduler>.coefficients;
+    `next_input_scale` = the scheduler's scale_model_input factor of the next step (1 for DDPM / DDIM)."""
     _chk16(eps2, model_in2)
     _chk32(x, noise)
     k_x, k_e, c_x0, c_xt, sigma = coeffs
     n = x.numel()
-    _lib.check(_lib.load().lavie_cfg_ddpm_step(_p(eps2), _p(x), _p(noise), _p(model_in2), n, float(guidance), float(k_x),
-                                               float(k_e), float(c_x0), float(c_xt), float(sigma), _stream()),
-               "lavie_cfg_ddpm_step")
+    _lib.check(_lib.load().lavie_cfg_sampler_step(_p(eps2), _p(x), _p(noise), _p(model_in2), n, float(guidance), float(k_x),
+                                                  float(k_e), float(c_x0), float(c_xt), float(sigma),
+                                                  float(next_input_scale), _stream()),
+               "lavie_cfg_sampler_step")
 
 
-def latents_to_model_input(x, model_in2):
+def latents_to_model_input(x, model_in2, input_scale: float = 1.0):
     _chk32(x)
     _chk16(model_in2)
-    _lib.check(_lib.load().lavie_latents_to_model_input(_p(x), _p(model_in2), x.numel(), _stream()))
+    _lib.check(_lib.load().lavie_latents_to_scaled_model_input(_p(x), _p(model_in2), x.numel(), float(input_scale), _stream()))
 
 
 # ------------------------------------------------------------------ engine seams (sub-module forwards)

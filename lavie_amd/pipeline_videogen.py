@@ -118,7 +118,11 @@ class VideoGenPipeline:
         dev = latents.device
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps)
-        timesteps = [int(t) for t in sch.timesteps]
+        # Euler's timesteps are fractional (linspace) and reach the UNet as they are; DDPM / DDIM timesteps are integers
+        fractional = bool(getattr(sch, "fractional_timesteps", False))
+        timesteps = [float(t) if fractional else int(t) for t in sch.timesteps]
+        # scheduler.scale_model_input (pipeline_videogen.py:667) as a scalar the fused kernel applies to the fp16 model input
+        in_scale = getattr(sch, "model_input_scale", None)
         # `eta` goes to the scheduler only if its step takes one (DDIM), as prepare_extra_step_kwargs does
         # (pipeline_videogen.py:431-446); DDPM ignores it
         takes_eta = "eta" in inspect.signature(sch.coefficients).parameters
@@ -128,7 +132,7 @@ class VideoGenPipeline:
         x = latents.to(torch.float32).contiguous().clone()
         p = x.shape[0]
         model_in = torch.empty((2 * p,) + tuple(x.shape[1:]), dtype=torch.float16, device=dev)
-        ops.latents_to_model_input(x, model_in)
+        ops.latents_to_model_input(x, model_in, in_scale(timesteps[0]) if in_scale else 1.0)
         self.unet.prepare(2 * p, x.shape[2], x.shape[3], x.shape[4], ctx.shape[1])
 
         # per-step noise: drawn on the host only when the caller's generator lives there, then staged through
@@ -165,7 +169,8 @@ class VideoGenPipeline:
                     noise = staged[slot]
                 else:
                     noise = noise_dev.normal_(generator=generator) if generator is not None else noise_dev.normal_()
-            ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs)           # lines 679-683 fused
+            next_scale = in_scale(timesteps[i + 1]) if in_scale and i + 1 < len(timesteps) else 1.0
+            ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs, next_scale)   # lines 667, 679-683 fused
             if host_noise and coeffs[4] != 0.0:
                 step_done[slot] = torch.cuda.Event()
                 step_done[slot].record(main)

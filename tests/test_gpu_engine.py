@@ -342,3 +342,26 @@ def test_pipeline_ddim_scheduler(small):
             z = torch.randn(lat.shape, generator=gen) if eta > 0 else None
             x = osch.step(guided, t, x, eta=eta, noise=z)
         assert rel_l2(out, x) < 3e-2, eta
+
+
+def test_pipeline_euler_scheduler(small):
+    """sample_method 'eulerdiscrete' (base/pipelines/sample.py:50-55): fractional timesteps, init_noise_sigma-scaled
+    latents, the sigma-scaled model input written by the fused step kernel — against the oracle loop (oracle/euler.py;
+    PARITY UNPINNED against diffusers, see its header)."""
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    from lavie_amd.scheduling_euler_discrete import EulerDiscreteScheduler
+    from oracle import unet_fp32 as O
+    from oracle.euler import cfg_euler_loop
+    net, sd = small
+    pipe = VideoGenPipeline(unet=net, scheduler=EulerDiscreteScheduler())
+    g = torch.Generator().manual_seed(23)
+    pe, ne = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    lat = torch.randn(1, 4, 4, 8, 8, generator=g)
+    seen = []
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=64, width=64, video_length=4,
+               num_inference_steps=4, guidance_scale=7.5, output_type="latent",
+               callback=lambda i, t, x: seen.append(t)).video.float().cpu()
+    assert seen == pytest.approx([999.0, 666.0, 333.0, 0.0])
+    fn = lambda x, t, c: O.unet_forward(sd, x, t, c, ocfg_small())
+    ref = cfg_euler_loop(fn, lat, pe.half().float(), ne.half().float(), num_steps=4, guidance_scale=7.5)
+    assert rel_l2(out, ref) < 3e-2

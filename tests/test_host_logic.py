@@ -189,3 +189,42 @@ def test_ddim_scheduler_matches_oracle_and_fused_form():
         DDIMScheduler().coefficients(981)                # set_timesteps not called
     with pytest.raises(NotImplementedError):
         DDIMScheduler(clip_sample=True)
+
+
+def test_euler_scheduler_matches_oracle_and_fused_form():
+    """EulerDiscreteScheduler mirror vs the independently written oracle tables; step() == fused-kernel coefficients;
+    scale_model_input / init_noise_sigma; the generic step loop == oracle loop on a toy denoiser."""
+    import numpy as np
+    from lavie_amd.scheduling_euler_discrete import EulerDiscreteScheduler
+    from oracle.euler import EulerSchedule, cfg_euler_loop
+    for n in (50, 7):
+        s, o = EulerDiscreteScheduler(), EulerSchedule()
+        s.set_timesteps(n)
+        o.set_timesteps(n)
+        assert np.allclose(s.timesteps.numpy(), o.timesteps, rtol=1e-6)
+        assert np.allclose(s._sigmas, o.sigmas, rtol=1e-6)
+        assert s.init_noise_sigma == pytest.approx(o.init_noise_sigma, rel=1e-6)
+        x, e = torch.randn(16, dtype=torch.float64), torch.randn(16, dtype=torch.float64)
+        for i in (0, n // 2, n - 1):
+            t = s.timesteps[i]
+            k_x, k_e, c0, ct, sigma = s.coefficients(t)
+            assert sigma == 0.0
+            fused = c0 * (k_x * x - k_e * e) + ct * x
+            assert torch.allclose(fused, s.step(e, t, x).prev_sample, rtol=1e-10, atol=1e-10)
+            assert torch.allclose(s.scale_model_input(x, t), x / (o.sigmas[i] ** 2 + 1) ** 0.5, rtol=1e-6)
+    with pytest.raises(ValueError):
+        s.coefficients(123.456)
+    g = torch.Generator().manual_seed(1)
+    W = torch.randn(4, 4, generator=g) * 0.2
+    toy = lambda x, t, c: torch.einsum("oc,bcfhw->bofhw", W, x) * (1 + t / 1000) + c.mean(dim=(1, 2)).reshape(-1, 1, 1, 1, 1)
+    lat, pe, ne = torch.randn(1, 4, 2, 4, 4, generator=g), torch.randn(1, 5, 3, generator=g), torch.randn(1, 5, 3, generator=g)
+    ref = cfg_euler_loop(toy, lat, pe, ne, num_steps=6, guidance_scale=3.0)
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(6)
+    x = lat * s.init_noise_sigma
+    ctx = torch.cat([ne, pe])
+    for t in s.timesteps:
+        xin = s.scale_model_input(torch.cat([x, x]), t)
+        eps = toy(xin, float(t), ctx)
+        x = s.step(eps[0:1] + 3.0 * (eps[1:2] - eps[0:1]), t, x).prev_sample
+    assert torch.allclose(x, ref, rtol=1e-4, atol=1e-4)
