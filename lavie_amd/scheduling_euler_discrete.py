@@ -44,7 +44,7 @@ class EulerDiscreteScheduler:
             raise NotImplementedError(f"{beta_schedule} is not implemented for EulerDiscreteScheduler")
         self.betas = betas
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
-        self._train_sigmas = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5, dtype=np.float64)
+        self._train_sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy().astype(np.float64)
         self.num_inference_steps: Optional[int] = None
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                                       beta_schedule=beta_schedule, prediction_type=prediction_type,
