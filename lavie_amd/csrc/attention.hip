@@ -42,7 +42,10 @@ struct AttTile {
 // tile and key tile less on the VALU, which paces this kernel at head dim 40.
 // SC: sparse-causal key/value addressing (AttnParams::sc_frames): key j of batch entry (b, f) is token j % D of frame
 // (b, 0) for j < D and of frame (b, max(f-1, 0)) for j >= D — a per-piece row lookup in the staging loads, nothing else.
-template <int DHP, int QT, int ABL = 0, bool LSUM = false, bool SC = false>
+// NDT: number of 16-wide output-dimension tiles that exist ((dh + 15) / 16) as a compile-time constant for the model's head
+// dims (40 -> 3, 80 -> 5, 160 -> 10); 0 = decided at run time.  The run-time test put a branch and an exposed
+// ds_read -> wait -> MFMA chain around every output tile of the P V product.
+template <int DHP, int QT, int ABL = 0, bool LSUM = false, bool SC = false, int NDT = 0>
 __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention_kernel(const AttnParams p) {
     using T = AttTile<DHP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
 
     const float sl2 = p.scale * 1.4426950408889634f;   // softmax scale folded with log2(e): p = exp2(s*sl2 - m)
     const int ntile = cdiv(p.Lk, ATT_KEYS);
-    const int ndt = (dh + 15) >> 4;
+    const int ndt = NDT ? NDT : (dh + 15) >> 4;
 
     // tile 0 -> LDS buffer 0, tile 1 -> registers
     load_tile(0);
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
         for (int kt2 = 0; kt2 < 2; ++kt2) {
 #pragma unroll
             for (int dt = 0; dt < T::DT; ++dt) {
-                if (dt < ndt) {
+                if (NDT ? dt < NDT : dt < ndt) {
                     const char* va = cV + (kt2 * 32 + g * 4 + (li >> 2)) * T::STRIDE + (dt * 16 + (li & 3) * 4) * 2;
                     const fp16x4_raw lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va));
                     const fp16x4_raw hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va + 16 * T::STRIDE));
@@ -317,10 +320,10 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
     }
 }
 
-template <int DHP, int QT, int ABL = 0, bool LSUM = false, bool SC = false>
+template <int DHP, int QT, int ABL = 0, bool LSUM = false, bool SC = false, int NDT = 0>
 static int launch_att(const AttnParams& p, hipStream_t stream) {
     using T = AttTile<DHP>;
-    auto kern = attention_kernel<DHP, QT, ABL, LSUM, SC>;
+    auto kern = attention_kernel<DHP, QT, ABL, LSUM, SC, NDT>;
     static bool attr_set = false;
     if (!attr_set) {
         LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
@@ -330,6 +333,26 @@ static int launch_att(const AttnParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(256), T::LDS_BYTES, stream, p);
     LAVIE_HIP(hipGetLastError());
     return 0;
+}
+
+// Kernel choice by head dim: the model's head dims (40, 80, 160; 64 for completeness) get the compile-time output-tile count.
+template <bool SC>
+static int dispatch_att(const AttnParams& p, bool big, bool lsum, hipStream_t stream) {
+    if (p.dh <= 64) {
+        if (lsum) {
+            if (p.dh == 40) return big ? launch_att<64, 2, 0, true, SC, 3>(p, stream) : launch_att<64, 1, 0, true, SC, 3>(p, stream);
+            return big ? launch_att<64, 2, 0, true, SC>(p, stream) : launch_att<64, 1, 0, true, SC>(p, stream);
+        }
+        if (p.dh == 64) return big ? launch_att<64, 2, 0, false, SC, 4>(p, stream) : launch_att<64, 1, 0, false, SC, 4>(p, stream);
+        return big ? launch_att<64, 2, 0, false, SC>(p, stream) : launch_att<64, 1, 0, false, SC>(p, stream);
+    }
+    if (p.dh <= 96) {
+        if (lsum) return big ? launch_att<96, 2, 0, true, SC>(p, stream) : launch_att<96, 1, 0, true, SC>(p, stream);
+        if (p.dh == 80) return big ? launch_att<96, 2, 0, false, SC, 5>(p, stream) : launch_att<96, 1, 0, false, SC, 5>(p, stream);
+        return big ? launch_att<96, 2, 0, false, SC>(p, stream) : launch_att<96, 1, 0, false, SC>(p, stream);
+    }
+    if (p.dh == 160) return big ? launch_att<160, 2, 0, false, SC, 10>(p, stream) : launch_att<160, 1, 0, false, SC, 10>(p, stream);
+    return big ? launch_att<160, 2, 0, false, SC>(p, stream) : launch_att<160, 1, 0, false, SC>(p, stream);
 }
 
 static int g_force_qt = 0;
@@ -347,16 +370,7 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
         LAVIE_CHECK(p.Lk == 2 * p.Lq && p.kv_batch_div == 1 && p.NBq % p.sc_frames == 0,
                     "sparse-causal attention: needs Lk = 2 Lq, kv_batch_div = 1, NB %% frames = 0 (Lq=%d Lk=%d NB=%d frames=%d)",
                     p.Lq, p.Lk, p.NBq, p.sc_frames);
-        const bool ls = p.dh % 16 != 0;
-        if (p.dh <= 64) {
-            if (ls) return big ? launch_att<64, 2, 0, true, true>(p, stream) : launch_att<64, 1, 0, true, true>(p, stream);
-            return big ? launch_att<64, 2, 0, false, true>(p, stream) : launch_att<64, 1, 0, false, true>(p, stream);
-        }
-        if (p.dh <= 96) {
-            if (ls) return big ? launch_att<96, 2, 0, true, true>(p, stream) : launch_att<96, 1, 0, true, true>(p, stream);
-            return big ? launch_att<96, 2, 0, false, true>(p, stream) : launch_att<96, 1, 0, false, true>(p, stream);
-        }
-        return big ? launch_att<160, 2, 0, false, true>(p, stream) : launch_att<160, 1, 0, false, true>(p, stream);
+        return dispatch_att<true>(p, big, p.dh % 16 != 0, stream);
     }
     if (g_force_qt == 0x12 && p.dh <= 64) return launch_att<64, 2, 1>(p, stream);
     if (g_force_qt == 0x22 && p.dh <= 64) return launch_att<64, 2, 2>(p, stream);
@@ -364,15 +378,7 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
     if (g_force_qt == 1 && p.dh <= 64) return launch_att<64, 1>(p, stream);
     if (g_force_qt == 4 && p.dh <= 64) return launch_att<64, 4>(p, stream);
     const bool lsum = p.dh % 16 != 0 && g_force_qt != 0x40;     // row sums on the matrix pipe (0x40: A/B switch, VALU sums)
-    if (p.dh <= 64) {
-        if (lsum) return big ? launch_att<64, 2, 0, true>(p, stream) : launch_att<64, 1, 0, true>(p, stream);
-        return big ? launch_att<64, 2>(p, stream) : launch_att<64, 1>(p, stream);
-    }
-    if (p.dh <= 96) {
-        if (lsum) return big ? launch_att<96, 2, 0, true>(p, stream) : launch_att<96, 1, 0, true>(p, stream);
-        return big ? launch_att<96, 2>(p, stream) : launch_att<96, 1>(p, stream);
-    }
-    return big ? launch_att<160, 2>(p, stream) : launch_att<160, 1>(p, stream);
+    return dispatch_att<false>(p, big, lsum, stream);
 }
 
 }  // namespace lavie
