@@ -3,7 +3,7 @@
 # roofline.traffic / MFMA busy.  Outputs under gpurun_out/; copy the summaries into profiles/ afterwards.
 # Usage: bash tools/collect_profiles.sh <tag>
 set -o pipefail
-TAG=${1:-r01_c}
+TAG=${1:-r01_d}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
