@@ -63,6 +63,16 @@ int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void
 /* [Cout, Cin, 3, 3] (PyTorch) -> rows of `ld_out` halfs in the implicit GEMM's K order (64-channel slab, tap,
  * channel): out[co, col0 + ((ci/64)*9 + ky*3+kx)*64 + ci%64].  Cin %% 64 == 0. */
 int lavie_pack_conv3x3_f16(const void* w, void* out, int Cout, int Cin, int ld_out, int col0, void* stream);
+/* Temporal convolution over the frame axis on channels-last token rows (b, f, pixel): nn.Conv3d(C, Cout, kernel (T,1,1),
+ * padding (T/2,0,0)), T = 3 or 5 — conv1 / conv2 of the VSR stage's ResnetBlock3DCNN (vsr/models/resnet.py:258-259, 274,
+ * 285, 309).  Same implicit GEMM as the 3x3 conv with a frame-tap table: tap t of row m reads row
+ * m + (t - T/2) * D, zeros outside the clip.  x [B*F*D, C], Wp [Cout, T*C] (lavie_pack_temporal_conv_f16 order),
+ * y / R [B*F*D, Cout]; bias2 [B, ldb2] is the per-video time-embedding projection (rows_per_batch = F*D). */
+int lavie_temporal_conv_f16(const void* x, int C, const void* Wp, const float* bias, const float* bias2, int ldb2,
+                            int rows_per_batch, const void* R, void* y, int B, int F, int D, int Cout, int taps,
+                            const void* zero_page, void* stream);
+/* [Cout, Cin, T, 1, 1] (PyTorch Conv3d) -> [Cout][T*Cin] in the implicit GEMM's K order (64-channel slab, tap, channel). */
+int lavie_pack_temporal_conv_f16(const void* w, void* out, int Cout, int Cin, int taps, void* stream);
 /* GEGLU projection [2*inner, K] (+ bias) -> 16-row value/gate interleave expected by lavie_linear_f16(geglu=1). */
 int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float* bias_out, int N, int K, void* stream);
 

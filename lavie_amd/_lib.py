@@ -34,6 +34,9 @@ SIGNATURES = {
                                    c_float_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p]),
     "lavie_pack_conv3x3_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "lavie_temporal_conv_f16": (c_int, [c_void_p, c_int, c_void_p, c_float_p, c_float_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                                         c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lavie_pack_temporal_conv_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lavie_pack_geglu_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_int, c_void_p]),
     "lavie_group_norm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float_p, c_float_p, c_float,
                                       c_int, c_float_p, c_void_p, c_void_p]),

@@ -102,6 +102,34 @@ int lavie_pack_conv3x3_f16(const void* w, void* out, int Cout, int Cin, int ld_o
     return launch_pack_conv3x3(H(w), H(out), Cout, Cin, ld_out, col0, g_tap_major == 0, S(stream));
 }
 
+int lavie_temporal_conv_f16(const void* x, int C, const void* Wp, const float* bias, const float* bias2, int ldb2,
+                            int rows_per_batch, const void* R, void* y, int B, int F, int D, int Cout, int taps,
+                            const void* zero_page, void* stream) {
+    LAVIE_CHECK(x && Wp && y && zero_page, "temporal_conv: null tensor");
+    LAVIE_CHECK(taps == 3 || taps == 5, "temporal_conv: taps=%d (3 or 5)", taps);
+    LAVIE_CHECK(C > 0 && C % IGEMM_BK == 0 && Cout % 64 == 0, "temporal_conv: channel counts must be multiples of %d", IGEMM_BK);
+    LAVIE_CHECK(B >= 1 && F >= 1 && D >= 1 && (long long)B * F * D * (C > Cout ? C : Cout) < (1ll << 31), "temporal_conv: bad shape");
+    LAVIE_CHECK(!bias2 || rows_per_batch > 0, "temporal_conv: bias2 needs rows_per_batch > 0");
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.W = H(Wp); p.C = H(y); p.ldc = Cout; p.bias = bias; p.bias2 = bias2; p.ldb2 = ldb2;
+    p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    p.R = H(R); p.ldr = Cout;
+    p.tframes = F; p.tpix = D;
+    p.Hi = p.Ho = 1; p.Wi = p.Wo = 1; p.stride = 1;          // unused in temporal mode (kept valid)
+    p.M = B * F * D; p.N = Cout; p.zero = H(zero_page);
+    IgemmSeg& sg = p.seg[0];
+    sg.src = H(x); sg.C = C; sg.c0 = 0; sg.nchunks = C / IGEMM_BK; sg.ntaps = taps;
+    p.nseg = 1; p.nk = taps * sg.nchunks; p.ldw = p.nk * IGEMM_BK; p.tap_major = 0;
+    if (int rc = op_slab(p, EPI_LINEAR, true)) return rc;
+    return launch_igemm(p, true, EPI_LINEAR, S(stream));
+}
+
+int lavie_pack_temporal_conv_f16(const void* w, void* out, int Cout, int Cin, int taps, void* stream) {
+    LAVIE_CHECK(w && out && (taps == 3 || taps == 5), "pack_temporal_conv: bad arguments");
+    return launch_pack_conv_taps(H(w), H(out), Cout, Cin, taps, taps * Cin, 0, true, S(stream));
+}
+
 int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float* bias_out, int N, int K, void* stream) {
     LAVIE_CHECK(w && w_out, "pack_geglu: null tensor");
     int rc = launch_pack_geglu_rows(H(w), H(w_out), N, K, S(stream));

@@ -322,26 +322,32 @@ int launch_fill_relpos_bias(const half_t* emb, const int* buckets, float* out, i
 // ------------------------------------------------------------------ weight repacking (load time)
 // [Cout][Cin][3][3] -> out[co * ld_out + col0 + k], k = ((ci/64)*9 + tap)*64 + ci%64 (chunked: slab-major,
 // tap-minor, the implicit GEMM's K order) or k = tap*Cin + ci (conv_out)
+// `taps` = 9 for the 3x3 convs, 3 / 5 for nn.Conv3d (T, 1, 1) weights [Cout][Cin][T][1][1] (same memory order)
 __global__ void pack_conv3x3_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin, int ld_out,
-                                    int col0, int chunked) {
+                                    int col0, int chunked, int taps) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)Cout * Cin * 9;
+    const long total = (long)Cout * Cin * taps;
     if (i >= total) return;
     const int ci = (int)(i % Cin);
-    const int tap = (int)((i / Cin) % 9);
-    const int co = (int)(i / ((long)Cin * 9));
-    const int k = chunked ? ((ci >> 6) * 9 + tap) * 64 + (ci & 63) : tap * Cin + ci;
-    out[(size_t)co * ld_out + col0 + k] = w[((size_t)co * Cin + ci) * 9 + tap];
+    const int tap = (int)((i / Cin) % taps);
+    const int co = (int)(i / ((long)Cin * taps));
+    const int k = chunked ? ((ci >> 6) * taps + tap) * 64 + (ci & 63) : tap * Cin + ci;
+    out[(size_t)co * ld_out + col0 + k] = w[((size_t)co * Cin + ci) * taps + tap];
+}
+
+int launch_pack_conv_taps(const half_t* w, half_t* out, int Cout, int Cin, int taps, int ld_out, int col0, bool chunked,
+                          hipStream_t stream) {
+    LAVIE_CHECK(!chunked || Cin % 64 == 0, "pack_conv: Cin=%d must be a multiple of 64", Cin);
+    const long total = (long)Cout * Cin * taps;
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, out, Cout, Cin,
+                       ld_out, col0, chunked ? 1 : 0, taps);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_pack_conv3x3(const half_t* w, half_t* out, int Cout, int Cin, int ld_out, int col0, bool chunked,
                         hipStream_t stream) {
-    LAVIE_CHECK(!chunked || Cin % 64 == 0, "pack_conv3x3: Cin=%d must be a multiple of 64", Cin);
-    const long total = (long)Cout * Cin * 9;
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, out, Cout, Cin,
-                       ld_out, col0, chunked ? 1 : 0);
-    LAVIE_HIP(hipGetLastError());
-    return 0;
+    return launch_pack_conv_taps(w, out, Cout, Cin, 9, ld_out, col0, chunked, stream);
 }
 
 __global__ void copy_rows_kernel(const half_t* __restrict__ src, int ld_src, half_t* __restrict__ dst, int ld_dst,

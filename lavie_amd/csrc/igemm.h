@@ -16,7 +16,7 @@ struct IgemmSeg {
     int C;        // row length (channels) of src
     int c0;       // first channel of this segment inside src rows
     int nchunks;  // number of 64-channel slabs
-    int ntaps;    // 9 or 1
+    int ntaps;    // 9 (3x3) or 1 (centre tap: fused 1x1 shortcut); temporal mode: 3 or 5 frame taps
 };
 
 struct IgemmParams {
@@ -46,6 +46,10 @@ struct IgemmParams {
     // Gather geometry (GATHER = true): output pixel grid [NI, Ho, Wo], source grid [NI, Hi, Wi],
     // virtual input grid (Hi << ups, Wi << ups) for the folded nearest-x2 upsample.
     int Ho, Wo, Hi, Wi, stride, ups;
+    // Temporal mode (tframes > 0; GATHER = true, 128-row kernel only): rows are tokens (b, f, pixel) with tpix pixels per
+    // frame, and tap t of a segment with ntaps = T reads row m + (t - T/2) * tpix, or zeros when frame f + t - T/2 falls
+    // outside [0, tframes) — nn.Conv3d with kernel (T, 1, 1), padding (T/2, 0, 0) (vsr/models/resnet.py:258-259, 274).
+    int tframes, tpix;
     int nseg;
     int tap_major;        // diagnostic: K order tap > slab instead of slab > tap (needs weights packed to match)
     IgemmSeg seg[IGEMM_MAX_SEG];

@@ -88,6 +88,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_kernel(const IgemmParam
     if constexpr (GATHER) {
         const int hw = p.Ho * p.Wo;
         const int Hv = p.Hi << p.ups, Wv = p.Wi << p.ups;
+        if (p.tframes > 0) {          // temporal taps: slot t of row m = the same pixel, t - T/2 frames away (or -1)
+            const int T_ = p.seg[0].ntaps;
+            for (int idx = tid; idx < T::BM * 9; idx += T::THREADS) {
+                const int row = idx / 9, tap = idx - row * 9;
+                int m = m0 + row;
+                m = m < p.M ? m : p.M - 1;
+                const int f = (m / p.tpix) % p.tframes;
+                const int ff = f + tap - (T_ >> 1);
+                tab[idx] = (tap < T_ && (unsigned)ff < (unsigned)p.tframes) ? m + (tap - (T_ >> 1)) * p.tpix : -1;
+            }
+        } else
         for (int idx = tid; idx < T::BM * 9; idx += T::THREADS) {
             const int row = idx / 9, tap = idx - row * 9;
             int m = m0 + row;
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_kernel(const IgemmParam
     int pv[T::AP];
     auto prepare_read = [&]() {
         if constexpr (GATHER) {
-            const int tp = sg.ntaps == 9 ? tap : 4;
+            const int tp = sg.ntaps == 1 ? 4 : tap;
 #pragma unroll
             for (int i = 0; i < T::AP; ++i) pv[i] = tab[arow[i] * 9 + tp];
         }
@@ -494,7 +505,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         return reduce_splits();
     }
     // 160x320 ping-pong kernel: forced (mode 3) or whenever the planner's rule holds for this problem at its split factor
-    if (p.N % 320 == 0 && (lo == 3 || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits)))) {
+    if (p.N % 320 == 0 && !(gather && p.tframes > 0) && (lo == 3 || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits)))) {
         if (int rc = launch_igemm_pp(p, gather, stream)) return rc;
         return reduce_splits();
     }

@@ -113,6 +113,30 @@ def conv3x3(x1, wp, bias, ni, hi, wi, x2=None, sc1=None, sc2=None, bias2=None, r
     return y
 
 
+def pack_temporal_conv(weight):
+    """nn.Conv3d weight [Cout, Cin, T, 1, 1] (T = 3 or 5) -> [Cout, T*Cin] in the implicit GEMM's K order."""
+    _chk16(weight)
+    cout, cin, taps = weight.shape[:3]
+    out = torch.empty(cout, taps * cin, dtype=torch.float16, device=weight.device)
+    _lib.check(_lib.load().lavie_pack_temporal_conv_f16(_p(weight.contiguous()), _p(out), cout, cin, taps, _stream()),
+               "lavie_pack_temporal_conv_f16")
+    return out
+
+
+def temporal_conv(x, wp, bias, b, frames, d, taps, bias2=None, residual=None):
+    """Conv3d (taps, 1, 1), padding (taps // 2, 0, 0), over the frame axis of token rows [(b f d), C] (the VSR stage's
+    ResnetBlock3DCNN convs); bias2 [b, Cout] = per-video time-embedding projection; see lavie_temporal_conv_f16."""
+    _chk16(x, wp, residual)
+    _chk32(bias, bias2)
+    cout = wp.shape[0]
+    y = torch.empty(b * frames * d, cout, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().lavie_temporal_conv_f16(_p(x), x.shape[1], _p(wp), _p(bias), _p(bias2), cout,
+                                                   frames * d if bias2 is not None else 0, _p(residual), _p(y), b, frames, d,
+                                                   cout, taps, _p(_zero_page(x.device)), _stream()),
+               "lavie_temporal_conv_f16")
+    return y
+
+
 def group_norm(x1, gamma, beta, nb, groups, eps, silu, x2=None):
     """GroupNorm (+SiLU) over rows; `nb` batches share statistics over rows/nb rows each."""
     _chk16(x1, x2)

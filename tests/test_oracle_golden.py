@@ -134,3 +134,12 @@ def test_interp_ddim_schedule_and_loop():
     got = D.ddim_sample_loop(unet, z2, xs2, fx["ctx"].float(), D.SpacedSchedule(fx["steps"]), 4.0)
     assert rel_l2(got, fx["y"]) < 1e-4
     assert torch.equal(got[0], got[1])
+
+
+# ------------------------------------------------------------------ VSR stage, first pieces
+def test_vsr_resnet_block_3dcnn():
+    from oracle import vsr_blocks as V
+    for c in G.load("vsr_resnet3dcnn.pt")["cases"]:
+        sd = G.synth16(c["shapes"], c["seed"], "r.")
+        got = V.resnet_block_3dcnn(sd, "r.", c["x"].float(), c["temb"].float())
+        assert rel_l2(got, c["y"]) < 1e-5, (c["c"], c["taps"])

@@ -189,3 +189,21 @@ def test_interpolation_ddim_loop_matches_reference_diffusion():
     ref = rd.create_diffusion("10").ddim_sample_loop(fwd_cfg, z.shape, z, progress=False, device="cpu", **kw)
     assert rel_l2(D.ddim_sample_loop(toy, z, xs, ctx, D.SpacedSchedule("10"), 4.0), ref) < 1e-6
     assert rel_l2(create_diffusion("10").ddim_sample_loop(fwd_cfg, z.shape, z, **kw), ref) < 1e-6
+
+
+def test_vsr_resnet_block_3dcnn_direct_import():
+    """vsr/models/resnet.py imports only torch / einops: the reference's own ResnetBlock3DCNN (tier T1)."""
+    import importlib.util
+    from oracle import vsr_blocks as V
+    spec = importlib.util.spec_from_file_location("ref_vsr_resnet", "/root/reference/vsr/models/resnet.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    g = torch.Generator().manual_seed(4)
+    for c, kern, frames in ((64, (5, 1, 1), 7), (128, (3, 1, 1), 2)):
+        blk = m.ResnetBlock3DCNN(in_channels=c, out_channels=c, kernel=kern, temb_channels=96).eval()
+        sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}, 5)
+        blk.load_state_dict(sd)
+        x, temb = torch.randn(2, c, frames, 4, 6, generator=g), torch.randn(2, 96, generator=g)
+        with torch.no_grad():
+            ref = blk(x, temb)
+        assert rel_l2(V.resnet_block_3dcnn(sd, "", x, temb), ref) < 1e-5

@@ -275,3 +275,23 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ablate_pp":
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ablate":
     bench_ablate()
     bench_ablate_gemm()
+
+
+def bench_tconv():
+    """(T,1,1) temporal convs of the VSR stage at its full size: 8-frame chunk at 320x512 (vsr/sample.py chunking), widths of
+    the VSR UNet levels."""
+    print(f"{'B':>2} {'F':>3} {'D':>7} {'C':>5} {'taps':>4} | us   TF/s   GB/s(algorithmic: x + y once)")
+    for F_, D, C, taps in ((8, 320 * 512, 256, 5), (8, 320 * 512, 256, 3), (8, 160 * 256, 512, 5), (8, 80 * 128, 512, 5),
+                           (8, 40 * 64, 1024, 5)):
+        x = rnd(F_ * D, C)
+        w = rnd(C, C, taps, 1, 1) / math.sqrt(C * taps)
+        wp = ops.pack_temporal_conv(w)
+        bias = torch.randn(C, device=dev)
+        us = timeit(lambda: ops.temporal_conv(x, wp, bias, 1, F_, D, taps), iters=10)
+        fl = 2.0 * F_ * D * C * C * taps
+        by = 2.0 * 2 * F_ * D * C
+        print(f"{1:>2} {F_:>3} {D:>7} {C:>5} {taps:>4} | {us:9.1f} {fl / us / 1e6:6.0f} {by / us / 1e3:6.0f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tconv":
+    bench_tconv()
