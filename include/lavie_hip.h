@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAVIE_ABI_VERSION 2
+#define LAVIE_ABI_VERSION 3
 #define LAVIE_MAX_LEVELS 8
 
 const char* lavie_last_error(void);
@@ -179,6 +179,13 @@ typedef struct lavie_unet_config {
      *                         relative-position bias, and no such tensors in the state dict (:525-533)
      *   ff_before_temporal  : block order spatial -> text -> feed-forward -> temporal (:566-606) */
     int sparse_causal_attn1, temporal_plain, ff_before_temporal;
+    /* Block variant of the VSR stage's UNet3DVSRModel (vsr/models/attention.py:314-594; 0 = base model):
+     *   vsr_blocks              : Transformer3DModel starts with a ResnetBlock3DCNN (3,1,1) without time embedding
+     *                             (`resblock_temporal`, :350, 395-398), the temporal attention tensors are named
+     *                             attn_temporal / norm_temporal, proj_in / proj_out are nn.Linear (:353, 383)
+     *   only_cross_attention[l] : attn1 of level l attends to the text context instead of the frame (:465-490, 558-561) */
+    int vsr_blocks;
+    int only_cross_attention[LAVIE_MAX_LEVELS];
 } lavie_unet_config;
 
 int lavie_unet_create(const lavie_unet_config* cfg, lavie_unet_t* out);

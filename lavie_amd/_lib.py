@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LEVELS = 8
 
 c_void_p, c_int, c_float, c_ll, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_char_p
@@ -21,6 +21,7 @@ class UNetConfigC(C.Structure):
         ("layers_per_block", c_int), ("heads", c_int), ("cross_attention_dim", c_int), ("norm_groups", c_int),
         ("norm_eps", c_float), ("rotary_dim", c_int), ("rel_buckets", c_int), ("rel_max_distance", c_int),
         ("sparse_causal_attn1", c_int), ("temporal_plain", c_int), ("ff_before_temporal", c_int),
+        ("vsr_blocks", c_int), ("only_cross_attention", c_int * MAX_LEVELS),
     ]
 
 

@@ -24,6 +24,9 @@ class UNetConfig:
     sparse_causal_attn1: bool = False    # use_first_frame: attn1 keys/values = first frame || previous frame
     temporal_plain: bool = False         # attn_temp without rotary embedding / relative-position bias
     ff_before_temporal: bool = False     # block order spatial -> text -> FF -> temporal
+    # Block variant of the VSR stage's UNet3DVSRModel (vsr/models/attention.py:314-594)
+    vsr_blocks: bool = False             # resblock_temporal in front, attn_temporal / norm_temporal names, Linear proj_in/out
+    only_cross_attention: Tuple[bool, ...] = ()      # per level: attn1 attends to the text context
 
     @property
     def time_embed_dim(self) -> int:

@@ -126,26 +126,38 @@ void UNet::build_param_list() {
         lin(p + ".to_q", ch, ch, false); lin(p + ".to_k", kv, ch, false); lin(p + ".to_v", kv, ch, false);
         lin(p + ".to_out.0", ch, ch, true);
     };
-    auto transformer = [&](const std::string& p, int ch) {
+    auto conv_t = [&](const std::string& p, int cin, int cout, int taps) { add(p + ".weight", {cout, cin, taps, 1, 1}); add(p + ".bias", {cout}); };
+    auto transformer = [&](const std::string& p, int ch, int level) {
+        const bool vsr = c.vsr_blocks != 0;
+        const bool cross1 = vsr && level >= 0 && c.only_cross_attention[level] != 0;
+        const std::string tname = vsr ? "temporal" : "temp";          // attn_temporal / norm_temporal in the VSR model
+        if (vsr) {                                                     // resblock_temporal: ResnetBlock3DCNN (3,1,1), no temb
+            affine(p + ".resblock_temporal.norm1", ch);
+            conv_t(p + ".resblock_temporal.conv1", ch, ch, 3);
+            affine(p + ".resblock_temporal.norm2", ch);
+            conv_t(p + ".resblock_temporal.conv2", ch, ch, 3);
+        }
         affine(p + ".norm", ch);
-        conv(p + ".proj_in", ch, ch, 1);
+        if (vsr) lin(p + ".proj_in", ch, ch, true); else conv(p + ".proj_in", ch, ch, 1);
         const std::string b = p + ".transformer_blocks.0";
-        attention(b + ".attn1", ch, ch);
+        attention(b + ".attn1", ch, cross1 ? c.cross_attention_dim : ch);
         affine(b + ".norm1", ch);
         attention(b + ".attn2", ch, c.cross_attention_dim);
         affine(b + ".norm2", ch);
-        attention(b + ".attn_temp", ch, ch);
+        attention(b + ".attn_" + tname, ch, ch);
         if (!c.temporal_plain) {
-            add(b + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight", {c.rel_buckets, c.heads});
-            add(b + ".attn_temp.rotary_emb.freqs", {c.rotary_dim / 2});
+            add(b + ".attn_" + tname + ".time_rel_pos_bias.relative_attention_bias.weight", {c.rel_buckets, c.heads});
+            add(b + ".attn_" + tname + ".rotary_emb.freqs", {c.rotary_dim / 2});
         }
-        affine(b + ".norm_temp", ch);
+        affine(b + ".norm_" + tname, ch);
         lin(b + ".ff.net.0.proj", ch, 8 * ch, true);
         lin(b + ".ff.net.2", 4 * ch, ch, true);
         affine(b + ".norm3", ch);
-        conv(p + ".proj_out", ch, ch, 1);
+        if (vsr) lin(p + ".proj_out", ch, ch, true); else conv(p + ".proj_out", ch, ch, 1);
         TransformerW t;
         t.prefix = p; t.C = ch;
+        t.tres.present = vsr;
+        t.attn1_cross = cross1;
         transformers_.push_back(t);
     };
     const int* widths = c.block_out_channels;
@@ -160,7 +172,7 @@ void UNet::build_param_list() {
             const std::string p = "down_blocks." + std::to_string(l);
             resnet(p + ".resnets." + std::to_string(j), cur, widths[l]);
             cur = widths[l];
-            if (c.attn_levels[l]) transformer(p + ".attentions." + std::to_string(j), cur);
+            if (c.attn_levels[l]) transformer(p + ".attentions." + std::to_string(j), cur, l);
             skips.push_back(cur);
         }
         if (l + 1 < L) {
@@ -169,7 +181,7 @@ void UNet::build_param_list() {
         }
     }
     resnet("mid_block.resnets.0", cur, cur);
-    transformer("mid_block.attentions.0", cur);
+    transformer("mid_block.attentions.0", cur, -1);      // the mid block always self-attends (vsr/models/unet.py:248-270)
     resnet("mid_block.resnets.1", cur, cur);
     for (int i = 0; i < L; ++i) {
         const int l = L - 1 - i;
@@ -179,7 +191,7 @@ void UNet::build_param_list() {
             skips.pop_back();
             resnet(p + ".resnets." + std::to_string(j), cur + sk, widths[l]);
             cur = widths[l];
-            if (c.attn_levels[l]) transformer(p + ".attentions." + std::to_string(j), cur);
+            if (c.attn_levels[l]) transformer(p + ".attentions." + std::to_string(j), cur, l);
         }
         if (i + 1 < L) conv(p + ".upsamplers.0.conv", cur, cur, 3);
     }
@@ -288,7 +300,9 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
     RUN(pack_linear(p + ".proj_out", C, C, true, &t->pout, s));
     RUN(pack_norm(b + ".norm1", C, &t->ln1, s));
     RUN(pack_norm(b + ".norm2", C, &t->ln2, s));
-    RUN(pack_norm(b + ".norm_temp", C, &t->lnt, s));
+    const std::string tname = cfg_.vsr_blocks ? "temporal" : "temp";
+    RUN(pack_norm(b + ".norm_" + tname, C, &t->lnt, s));
+    if (t->tres.present) RUN(pack_temporal_res(p + ".resblock_temporal", C, 3, &t->tres, s));
     RUN(pack_norm(b + ".norm3", C, &t->ln3, s));
     auto fuse = [&](const std::string& a, const char* const* names, int count, int K, half_t** out) -> int {
         WALLOC(*out, half_t, (size_t)count * C * K);
@@ -303,15 +317,20 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
     static const char* const qkv[] = {"to_q", "to_k", "to_v"};
     static const char* const kv[] = {"to_k", "to_v"};
     static const char* const qonly[] = {"to_q"};
-    RUN(fuse(b + ".attn1", qkv, 3, C, &t->wqkv1));
+    if (t->attn1_cross) {
+        RUN(fuse(b + ".attn1", qonly, 1, C, &t->wq1));
+        RUN(fuse(b + ".attn1", kv, 2, X, &t->wkv1));
+    } else {
+        RUN(fuse(b + ".attn1", qkv, 3, C, &t->wqkv1));
+    }
     RUN(pack_linear(b + ".attn1.to_out.0", C, C, true, &t->o1, s));
     RUN(fuse(b + ".attn2", qonly, 1, C, &t->wq2));
     RUN(fuse(b + ".attn2", kv, 2, X, &t->wkv2));
     RUN(pack_linear(b + ".attn2.to_out.0", C, C, true, &t->o2, s));
-    RUN(fuse(b + ".attn_temp", qkv, 3, C, &t->wqkvt));
-    RUN(pack_linear(b + ".attn_temp.to_out.0", C, C, true, &t->ot, s));
+    RUN(fuse(b + ".attn_" + tname, qkv, 3, C, &t->wqkvt));
+    RUN(pack_linear(b + ".attn_" + tname + ".to_out.0", C, C, true, &t->ot, s));
     if (!cfg_.temporal_plain) {
-        const std::string key = b + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight";
+        const std::string key = b + ".attn_" + tname + ".time_rel_pos_bias.relative_attention_bias.weight";
         const half_t* e = given(key);
         NEED(e, key);
         const size_t n = (size_t)cfg_.rel_buckets * cfg_.heads;
@@ -339,7 +358,8 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
         WALLOC(*bv, float, N);
         return launch_ln_fold(W, ln.g, ln.b, bias, *Wf, *sv, *bv, N, C, s);
     };
-    RUN(fold(t->wqkv1, t->ln1, nullptr, 3 * C, &t->f_qkv1, &t->s_qkv1, &t->b_qkv1));
+    if (t->attn1_cross) RUN(fold(t->wq1, t->ln1, nullptr, C, &t->f_q1, &t->s_q1, &t->b_q1));
+    else RUN(fold(t->wqkv1, t->ln1, nullptr, 3 * C, &t->f_qkv1, &t->s_qkv1, &t->b_qkv1));
     RUN(fold(t->wq2, t->ln2, nullptr, C, &t->f_q2, &t->s_q2, &t->b_q2));
     RUN(fold(t->wqkvt, t->lnt, nullptr, 3 * C, &t->f_qkvt, &t->s_qkvt, &t->b_qkvt));
     {
@@ -355,6 +375,28 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
         RUN(launch_pack_geglu_vec(tmps, t->s_ff1, 8 * C, s));
         RUN(launch_pack_geglu_vec(tmpb, t->b_ff1, 8 * C, s));
     }
+    return 0;
+}
+
+int UNet::pack_temporal_res(const std::string& prefix, int C, int taps1, TemporalResW* out, hipStream_t s) {
+    out->present = true;
+    out->taps1 = taps1;
+    RUN(pack_norm(prefix + ".norm1", C, &out->n1, s));
+    RUN(pack_norm(prefix + ".norm2", C, &out->n2, s));
+    const half_t* w1 = given(prefix + ".conv1.weight");
+    const half_t* b1 = given(prefix + ".conv1.bias");
+    const half_t* w2 = given(prefix + ".conv2.weight");
+    const half_t* b2 = given(prefix + ".conv2.bias");
+    NEED(w1, prefix + ".conv1.weight"); NEED(b1, prefix + ".conv1.bias");
+    NEED(w2, prefix + ".conv2.weight"); NEED(b2, prefix + ".conv2.bias");
+    WALLOC(out->w1, half_t, (size_t)C * taps1 * C);
+    WALLOC(out->w2, half_t, (size_t)C * 3 * C);
+    WALLOC(out->b1, float, C);
+    WALLOC(out->b2, float, C);
+    RUN(launch_pack_conv_taps(w1, out->w1, C, C, taps1, taps1 * C, 0, true, s));
+    RUN(launch_pack_conv_taps(w2, out->w2, C, C, 3, 3 * C, 0, true, s));
+    RUN(launch_f16_to_f32(b1, out->b1, C, s));
+    RUN(launch_f16_to_f32(b2, out->b2, C, s));
     return 0;
 }
 
@@ -553,6 +595,48 @@ static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsr
     return rc;
 }
 
+// (taps,1,1) temporal conv over the frame axis of token rows [(b f d), C] (IgemmParams temporal mode; 128-row kernel).
+static int tconv(FwdCtx& c, const half_t* x, int C, const half_t* W, const float* bias, const float* bias2, int ldb2,
+                 const half_t* R, half_t* y, int D, int Cout, int taps, const half_t* zero) {
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.W = W; p.ldw = taps * C; p.C = y; p.ldc = Cout; p.bias = bias; p.bias2 = bias2; p.ldb2 = ldb2;
+    p.rows_per_batch = c.F * D; p.R = R; p.ldr = Cout;
+    p.tframes = c.F; p.tpix = D;
+    p.Hi = p.Ho = 1; p.Wi = p.Wo = 1; p.stride = 1;
+    p.M = c.B * c.F * D; p.N = Cout; p.zero = zero;
+    LAVIE_CHECK(C % IGEMM_BK == 0, "temporal conv: channel count %d must be a multiple of %d", C, IGEMM_BK);
+    IgemmSeg& sg = p.seg[0];
+    sg.src = x; sg.C = C; sg.c0 = 0; sg.nchunks = C / IGEMM_BK; sg.ntaps = taps;
+    p.nseg = 1;
+    p.nk = taps * sg.nchunks;
+    p.splits = igemm_plan_splits_gather(p);
+    const size_t mark = c.ws->mark();
+    if (p.splits > 1) {
+        p.slab = (float*)c.ws->alloc((size_t)p.splits * p.M * p.N * sizeof(float));
+        if (!c.dry) LAVIE_CHECK(p.slab != nullptr, "workspace exhausted (split-K slab)");
+    }
+    const int rc = c.dry ? 0 : launch_igemm(p, true, EPI_LINEAR, c.s);
+    c.ws->release(mark);
+    return rc;
+}
+
+// ResnetBlock3DCNN without time embedding, in place on x (vsr/models/resnet.py:283-315; attention.py:350, 395-398):
+// GroupNorm statistics span the whole video (5-D input), eps 1e-6.
+int UNet::run_temporal_res(FwdCtx& c, const TemporalResW& r, half_t* x, int C, int D) {
+    const size_t M = (size_t)c.B * c.F * D;
+    const int P = c.F * D;
+    const size_t mark = c.ws->mark();
+    WS(nrm, half_t, M * C);
+    WS(h1, half_t, M * C);
+    LAUNCH(launch_group_norm(x, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n1.g, r.n1.b, 1e-6f, true, c.gn_ws, nrm, c.s));
+    RUN(tconv(c, nrm, C, r.w1, r.b1, nullptr, 0, nullptr, h1, D, C, r.taps1, zero_page_));
+    LAUNCH(launch_group_norm(h1, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n2.g, r.n2.b, 1e-6f, true, c.gn_ws, nrm, c.s));
+    RUN(tconv(c, nrm, C, r.w2, r.b2, nullptr, 0, x, x, D, C, 3, zero_page_));
+    c.ws->release(mark);
+    return 0;
+}
+
 int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, const float* tproj,
                      int ld_tproj, half_t* y, int H, int W) {
     LAVIE_CHECK(C1 + C2 == r.cin, "resnet %s: got %d+%d input channels, expected %d", r.prefix.c_str(), C1, C2, r.cin);
@@ -599,6 +683,8 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     WS(kv2, half_t, (size_t)c.B * c.ctx_len * 2 * C);
     const size_t ti = &t - transformers_.data();
 
+    // VSR: ResnetBlock3DCNN (3,1,1) on the block input, before the residual is taken (vsr/models/attention.py:395-400)
+    if (t.tres.present) RUN(run_temporal_res(c, t.tres, x, C, D));
     // per-frame GroupNorm (eps 1e-6) + 1x1 proj_in (attention.py:369-373)
     LAUNCH(launch_group_norm(x, C, nullptr, 0, NI, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s));
     // LayerNorm folding: the GEMM that produces the residual stream `tx` also emits per-row (sum, sum^2) partials of
@@ -618,23 +704,41 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     }
     RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, T, EPI_LINEAR, nullptr, rowstat));
 
-    // spatial self-attention (attention.py:513-522)
-    if (fold) {
-        lf.s = t.s_qkv1;
-        RUN(linear(c, tx, C, t.f_qkv1, t.b_qkv1, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
-    } else {
-        LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, T, C, 1e-5f, c.s));
-        RUN(linear(c, ln, C, t.wqkv1, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
-    }
-    if (!c.dry) {
-        AttnParams a;
-        a.q = wide; a.ldq = 3 * C; a.k = wide + C; a.ldk = 3 * C; a.v = wide + 2 * C; a.ldv = 3 * C;
-        a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = D; a.heads = heads; a.dh = dh; a.kv_batch_div = 1; a.scale = scale;
-        if (cfg_.sparse_causal_attn1) {      // keys/values = first frame || previous frame (interpolation attention.py:630-639)
-            a.Lk = 2 * D;
-            a.sc_frames = c.F;
+    if (t.attn1_cross) {
+        // VSR only_cross_attention levels: attn1 attends to the text context (vsr/models/attention.py:558-561)
+        if (fold) {
+            lf.s = t.s_q1;
+            RUN(linear(c, tx, C, t.f_q1, t.b_q1, C, C, nullptr, wide, C, T, EPI_LINEAR, &lf));
+        } else {
+            LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, T, C, 1e-5f, c.s));
+            RUN(linear(c, ln, C, t.wq1, nullptr, C, C, nullptr, wide, C, T));
         }
-        RUN(launch_attention(a, c.s));
+        RUN(linear(c, ctx, X, t.wkv1, nullptr, 2 * C, X, nullptr, kv2, 2 * C, c.B * c.ctx_len));
+        if (!c.dry) {
+            AttnParams a;
+            a.q = wide; a.ldq = C; a.k = kv2; a.ldk = 2 * C; a.v = kv2 + C; a.ldv = 2 * C;
+            a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = c.ctx_len; a.heads = heads; a.dh = dh; a.kv_batch_div = c.F; a.scale = scale;
+            RUN(launch_attention(a, c.s));
+        }
+    } else {
+        // spatial self-attention (attention.py:513-522)
+        if (fold) {
+            lf.s = t.s_qkv1;
+            RUN(linear(c, tx, C, t.f_qkv1, t.b_qkv1, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
+        } else {
+            LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, T, C, 1e-5f, c.s));
+            RUN(linear(c, ln, C, t.wqkv1, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+        }
+        if (!c.dry) {
+            AttnParams a;
+            a.q = wide; a.ldq = 3 * C; a.k = wide + C; a.ldk = 3 * C; a.v = wide + 2 * C; a.ldv = 3 * C;
+            a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = D; a.heads = heads; a.dh = dh; a.kv_batch_div = 1; a.scale = scale;
+            if (cfg_.sparse_causal_attn1) {      // keys/values = first frame || previous frame (interpolation attention.py:630-639)
+                a.Lk = 2 * D;
+                a.sc_frames = c.F;
+            }
+            RUN(launch_attention(a, c.s));
+        }
     }
     RUN(linear(c, att, C, t.o1.w, t.o1.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
 

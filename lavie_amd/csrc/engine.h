@@ -51,9 +51,23 @@ struct ResnetW {
     int temb_off = 0;                               // column of this block inside the fused time_emb_proj output
 };
 
+// ResnetBlock3DCNN (vsr/models/resnet.py:220-315): GroupNorm + SiLU -> (T,1,1) conv -> GroupNorm + SiLU -> (3,1,1) conv
+struct TemporalResW {
+    bool present = false;
+    int taps1 = 3;
+    NormW n1, n2;
+    half_t* w1 = nullptr; float* b1 = nullptr;      // [C][taps1 * C]
+    half_t* w2 = nullptr; float* b2 = nullptr;      // [C][3 * C]
+};
+
 struct TransformerW {
     std::string prefix;
     int C = 0;
+    // VSR variant (lavie_unet_config::vsr_blocks / only_cross_attention)
+    TemporalResW tres;                              // `resblock_temporal`, runs before the block's residual is taken
+    bool attn1_cross = false;                       // attn1 attends to the text context
+    half_t* wq1 = nullptr; half_t* wkv1 = nullptr;  // its projections: [C][C], [2C][cross_dim]
+    half_t* f_q1 = nullptr; float* s_q1 = nullptr; float* b_q1 = nullptr;
     NormW gn, ln1, ln2, lnt, ln3;
     LinW pin, pout;
     half_t* wqkv1 = nullptr; LinW o1;
@@ -98,6 +112,8 @@ private:
     int pack_linear(const std::string& prefix, int N, int K, bool bias, LinW* out, hipStream_t s);
     int pack_resnet(ResnetW* r, hipStream_t s);
     int pack_transformer(TransformerW* t, hipStream_t s);
+    int pack_temporal_res(const std::string& prefix, int C, int taps1, TemporalResW* out, hipStream_t s);
+    int run_temporal_res(FwdCtx& c, const TemporalResW& r, half_t* x, int C, int D);
     int pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s);
     int ensure_tables(int F, hipStream_t s);
 

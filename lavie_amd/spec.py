@@ -44,23 +44,37 @@ def _attention(prefix: str, c: int, kv_dim: int) -> Iterator[Tuple[str, Shape]]:
     yield from _linear(prefix + ".to_out.0", c, c)
 
 
-def _transformer(prefix: str, c: int, cfg: UNetConfig) -> Iterator[Tuple[str, Shape]]:
+def _temporal_conv(prefix: str, cin: int, cout: int, taps: int) -> Iterator[Tuple[str, Shape]]:
+    yield prefix + ".weight", (cout, cin, taps, 1, 1)
+    yield prefix + ".bias", (cout,)
+
+
+def _transformer(prefix: str, c: int, cfg: UNetConfig, level: int = -1) -> Iterator[Tuple[str, Shape]]:
+    """`level` = -1 for the mid block, which always self-attends."""
+    vsr = cfg.vsr_blocks
+    cross1 = vsr and level >= 0 and bool(cfg.only_cross_attention[level])
+    tname = "temporal" if vsr else "temp"
+    if vsr:                                   # resblock_temporal (vsr/models/attention.py:350): ResnetBlock3DCNN, no temb
+        yield from _affine(prefix + ".resblock_temporal.norm1", c)
+        yield from _temporal_conv(prefix + ".resblock_temporal.conv1", c, c, 3)
+        yield from _affine(prefix + ".resblock_temporal.norm2", c)
+        yield from _temporal_conv(prefix + ".resblock_temporal.conv2", c, c, 3)
     yield from _affine(prefix + ".norm", c)
-    yield from _conv(prefix + ".proj_in", c, c, 1)
+    yield from (_linear(prefix + ".proj_in", c, c) if vsr else _conv(prefix + ".proj_in", c, c, 1))
     blk = prefix + ".transformer_blocks.0"
-    yield from _attention(blk + ".attn1", c, c)
+    yield from _attention(blk + ".attn1", c, cfg.cross_attention_dim if cross1 else c)
     yield from _affine(blk + ".norm1", c)
     yield from _attention(blk + ".attn2", c, cfg.cross_attention_dim)
     yield from _affine(blk + ".norm2", c)
-    yield from _attention(blk + ".attn_temp", c, c)
+    yield from _attention(blk + f".attn_{tname}", c, c)
     if not cfg.temporal_plain:
-        yield blk + ".attn_temp.time_rel_pos_bias.relative_attention_bias.weight", (cfg.rel_buckets, cfg.heads)
-        yield blk + ".attn_temp.rotary_emb.freqs", (cfg.rotary_dim // 2,)
-    yield from _affine(blk + ".norm_temp", c)
+        yield blk + f".attn_{tname}.time_rel_pos_bias.relative_attention_bias.weight", (cfg.rel_buckets, cfg.heads)
+        yield blk + f".attn_{tname}.rotary_emb.freqs", (cfg.rotary_dim // 2,)
+    yield from _affine(blk + f".norm_{tname}", c)
     yield from _linear(blk + ".ff.net.0.proj", c, 8 * c)
     yield from _linear(blk + ".ff.net.2", 4 * c, c)
     yield from _affine(blk + ".norm3", c)
-    yield from _conv(prefix + ".proj_out", c, c, 1)
+    yield from (_linear(prefix + ".proj_out", c, c) if vsr else _conv(prefix + ".proj_out", c, c, 1))
 
 
 def iter_params(cfg: UNetConfig = BASE_CONFIG) -> Iterator[Tuple[str, Shape]]:
@@ -78,7 +92,7 @@ def iter_params(cfg: UNetConfig = BASE_CONFIG) -> Iterator[Tuple[str, Shape]]:
             yield from _resnet(f"down_blocks.{lvl}.resnets.{j}", cur, width, temb)
             cur = width
             if cfg.attn_levels[lvl]:
-                yield from _transformer(f"down_blocks.{lvl}.attentions.{j}", cur, cfg)
+                yield from _transformer(f"down_blocks.{lvl}.attentions.{j}", cur, cfg, lvl)
             skips.append(cur)
         if lvl + 1 < levels:
             yield from _conv(f"down_blocks.{lvl}.downsamplers.0.conv", cur, cur, 3)
@@ -94,7 +108,7 @@ def iter_params(cfg: UNetConfig = BASE_CONFIG) -> Iterator[Tuple[str, Shape]]:
             yield from _resnet(f"up_blocks.{i}.resnets.{j}", cur + skips.pop(), widths[lvl], temb)
             cur = widths[lvl]
             if cfg.attn_levels[lvl]:
-                yield from _transformer(f"up_blocks.{i}.attentions.{j}", cur, cfg)
+                yield from _transformer(f"up_blocks.{i}.attentions.{j}", cur, cfg, lvl)
         if i + 1 < levels:
             yield from _conv(f"up_blocks.{i}.upsamplers.0.conv", cur, cur, 3)
 

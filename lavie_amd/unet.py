@@ -42,6 +42,7 @@ class UNet3DConditionModel(nn.Module):
     # transformer-block variant (UNetConfig fields); lavie_amd.interpolation.unet overrides it
     _block_variant = dict(sparse_causal_attn1=False, temporal_plain=False, ff_before_temporal=False)
     _allow_first_frame = False
+    _allow_vsr_options = False            # only_cross_attention tuples / use_linear_projection (lavie_amd.vsr.unet)
 
     def __init__(
         self,
@@ -79,8 +80,10 @@ class UNet3DConditionModel(nn.Module):
         super().__init__()
         # options that leave the benchmarked inference path (SURVEY.md §8a "Not on the path")
         unsupported = {
-            "center_input_sample": center_input_sample, "only_cross_attention": only_cross_attention,
-            "dual_cross_attention": dual_cross_attention, "use_linear_projection": use_linear_projection,
+            "center_input_sample": center_input_sample,
+            "only_cross_attention": only_cross_attention and not self._allow_vsr_options,
+            "dual_cross_attention": dual_cross_attention,
+            "use_linear_projection": use_linear_projection and not self._allow_vsr_options,
             "class_embed_type": class_embed_type, "num_class_embeds": num_class_embeds,
             "upcast_attention": upcast_attention, "use_first_frame": use_first_frame and not self._allow_first_frame,
             "use_relative_position": use_relative_position,
@@ -105,7 +108,8 @@ class UNet3DConditionModel(nn.Module):
                               block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
                               heads=attention_head_dim, cross_attention_dim=cross_attention_dim,
                               norm_groups=norm_num_groups, norm_eps=norm_eps, attn_levels=attn,
-                              **dict(self._block_variant, sparse_causal_attn1=bool(use_first_frame) and self._allow_first_frame))
+                              **dict(self._block_variant, sparse_causal_attn1=bool(use_first_frame) and self._allow_first_frame),
+                              **self._vsr_config(only_cross_attention, use_linear_projection, len(block_out_channels)))
         self.cfg.validate()
         self.config = SimpleNamespace(
             sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
@@ -128,6 +132,10 @@ class UNet3DConditionModel(nn.Module):
         self._engine = None
         self._engine_key = None
         self._prepared = None
+
+    def _vsr_config(self, only_cross_attention, use_linear_projection, levels: int) -> dict:
+        """UNetConfig fields of the VSR block variant; the base and interpolation models have none."""
+        return {}
 
     # ------------------------------------------------------------------ init / bookkeeping
     @staticmethod
@@ -189,6 +197,9 @@ class UNet3DConditionModel(nn.Module):
         c.rotary_dim, c.rel_buckets, c.rel_max_distance = cfg.rotary_dim, cfg.rel_buckets, cfg.rel_max_distance
         c.sparse_causal_attn1, c.temporal_plain = int(cfg.sparse_causal_attn1), int(cfg.temporal_plain)
         c.ff_before_temporal = int(cfg.ff_before_temporal)
+        c.vsr_blocks = int(cfg.vsr_blocks)
+        for i, v in enumerate(cfg.only_cross_attention):
+            c.only_cross_attention[i] = int(v)
         return c
 
     def _ensure_engine(self):

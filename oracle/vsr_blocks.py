@@ -32,3 +32,48 @@ def resnet_block_3dcnn(sd: SD, p: str, x, temb, groups: int = 32, eps: float = 1
     h = F.silu(F.group_norm(h, groups, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps))
     h = temporal_conv(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"])
     return x + h
+
+
+# --------------------------------------------------------------------------- VSR Transformer3DModel
+def vsr_transformer_block(sd: SD, p: str, x, ctx, frames: int, heads: int, only_cross_attention: bool, ucfg):
+    """vsr/models/attention.py:552-594 (eval): attn1 is text cross-attention on `only_cross_attention` levels and spatial
+    self-attention otherwise; then text cross-attention, temporal attention (scale -> rotary -> + relative-position bias
+    -> softmax, :728-775: the base model's TemporalAttention under the names attn_temporal / norm_temporal), feed-forward."""
+    from . import unet_fp32 as O
+    n1 = O.layer_norm(sd, p + "norm1.", x)
+    x = x + O.cross_attention(sd, p + "attn1.", n1, ctx if only_cross_attention else None, heads)
+    x = x + O.cross_attention(sd, p + "attn2.", O.layer_norm(sd, p + "norm2.", x), ctx, heads)
+    bf, d, c = x.shape
+    xt = x.reshape(bf // frames, frames, d, c).permute(0, 2, 1, 3).reshape(-1, frames, c)
+    nt = O.layer_norm(sd, p + "norm_temporal.", xt)
+    xt = xt + O.temporal_attention(sd, p + "attn_temporal.", nt, ucfg)
+    x = xt.reshape(bf // frames, d, frames, c).permute(0, 2, 1, 3).reshape(bf, d, c)
+    return x + O.geglu_ff(sd, p + "ff.", O.layer_norm(sd, p + "norm3.", x))
+
+
+def vsr_transformer3d(sd: SD, p: str, x, ctx, heads: int = 8, only_cross_attention: bool = False, groups: int = 32):
+    """vsr/models/attention.py:386-439 with use_linear_projection=True: ResnetBlock3DCNN (3,1,1) without time embedding
+    (:350, 395-398), THEN the residual is taken (:400); per-frame GroupNorm eps 1e-6, Linear proj_in on tokens, one block,
+    Linear proj_out, + residual."""
+    from . import unet_fp32 as O
+    b, c, f, h, w = x.shape
+    x = resnet_block_3dcnn_no_temb(sd, p + "resblock_temporal.", x, groups)
+    frames_ = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    ctx_rep = ctx.repeat_interleave(f, dim=0)
+    t = F.group_norm(frames_, groups, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+    t = t.permute(0, 2, 3, 1).reshape(b * f, h * w, c)
+    t = F.linear(t, sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
+    ucfg = O.UNetConfig(heads=heads)
+    t = vsr_transformer_block(sd, p + "transformer_blocks.0.", t, ctx_rep, f, heads, only_cross_attention, ucfg)
+    t = F.linear(t, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    t = t.reshape(b * f, h, w, c).permute(0, 3, 1, 2) + frames_
+    return t.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4)
+
+
+def resnet_block_3dcnn_no_temb(sd: SD, p: str, x, groups: int = 32, eps: float = 1e-6):
+    """ResnetBlock3DCNN with temb_channels=None (vsr/models/attention.py:350): no time-embedding term."""
+    h = F.silu(F.group_norm(x, groups, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps))
+    h = temporal_conv(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"])
+    h = F.silu(F.group_norm(h, groups, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps))
+    h = temporal_conv(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"])
+    return x + h

@@ -42,6 +42,26 @@ def main():
         cases.append(dict(c=c, taps=kern[0], shapes=shapes, seed=seed, x=x.half(), temb=temb.half(), y=blk(x, temb)))
     save("vsr_resnet3dcnn.pt", dict(cases=cases))
 
+    # VSR Transformer3DModel (vsr/models/attention.py:314-594, under tests/refshim): resblock_temporal in front, attn1 as text
+    # cross-attention (only_cross_attention levels) or spatial self-attention, Linear projections, temporal attention with
+    # rotary + relative-position bias; widths / head dims of the VSR UNet (512 -> 64, 1024 -> 128), context width 1024
+    import refimport
+    mv = refimport.load_vsr_blocks()                    # puts tests/refshim on sys.path
+    from rotary_embedding_torch import RotaryEmbedding
+    cases = []
+    for c, only_cross, frames, h, w in ((512, True, 8, 4, 4), (1024, False, 5, 2, 4)):
+        tr = mv.attention.Transformer3DModel(8, c // 8, in_channels=c, num_layers=1, cross_attention_dim=1024,
+                                             norm_num_groups=32, use_linear_projection=True, only_cross_attention=only_cross,
+                                             rotary_emb=RotaryEmbedding(32)).eval()
+        shapes = module_shapes(tr)
+        seed = 950 + c
+        tr.load_state_dict(synth16(shapes, seed))
+        x = q16(torch.randn(2, c, frames, h, w, generator=g) * torch.linspace(0.5, 2.0, frames).reshape(1, 1, frames, 1, 1))
+        ctx = q16(torch.randn(2, 77, 1024, generator=g))
+        cases.append(dict(c=c, only_cross=only_cross, shapes=shapes, seed=seed, x=x.half(), ctx=ctx.half(),
+                          y=tr(x, encoder_hidden_states=ctx).sample))
+    save("vsr_transformer3d.pt", dict(cases=cases))
+
 
 if __name__ == "__main__":
     main()

@@ -59,3 +59,22 @@ def load_interp_diffusion():
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_vsr_blocks():
+    """vsr/models/{resnet,attention}.py under the shim (the VSR UNet file itself needs torchvision, absent here)."""
+    pkgname, root = "refmodels_vsr", "/root/reference/vsr/models"
+    if f"{pkgname}.attention" in sys.modules:
+        return sys.modules[pkgname]
+    if _SHIM not in sys.path:
+        sys.path.insert(0, _SHIM)
+    pkg = importlib.util.module_from_spec(importlib.machinery.ModuleSpec(pkgname, None, is_package=True))
+    pkg.__path__ = [root]
+    sys.modules[pkgname] = pkg
+    for name in ("resnet", "attention"):
+        spec = importlib.util.spec_from_file_location(f"{pkgname}.{name}", os.path.join(root, f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"{pkgname}.{name}"] = mod
+        spec.loader.exec_module(mod)
+        setattr(pkg, name, mod)
+    return pkg

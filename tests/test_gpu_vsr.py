@@ -60,3 +60,27 @@ def test_vsr_resnet_block_3dcnn_golden():
         n2 = ops.group_norm(h1, sd["norm2.weight"], sd["norm2.bias"], b, 32, 1e-6, True)
         y = ops.temporal_conv(n2, w2, sd["conv2.bias"], b, frames, d, 3, residual=xr)
         assert rel_l2(from_rows(y.float().cpu(), b, frames, h, w), c["y"]) < TOL_BLOCK, (C, c["taps"], frames)
+
+
+def test_vsr_transformer_golden():
+    """The VSR Transformer3DModel variant through the engine seam (lavie_unet_transformer_forward): temporal resblock,
+    attn1 as text cross-attention / self-attention, Linear projections — against the reference's outputs."""
+    from lavie_amd import ops, spec
+    from lavie_amd.config import UNetConfig
+    from lavie_amd.vsr import UNet3DVSRModel
+    for c in G.load("vsr_transformer3d.pt")["cases"]:
+        C, oc = c["c"], c["only_cross"]
+        cfg = UNetConfig(block_out_channels=(C,), attn_levels=(True,), layers_per_block=1, cross_attention_dim=1024,
+                         vsr_blocks=True, only_cross_attention=(oc,))
+        sd = G.synth16(spec.param_shapes(cfg), 5)
+        blk = G.synth16(c["shapes"], c["seed"], "down_blocks.0.attentions.0.")
+        assert set(blk) <= set(sd), set(blk) - set(sd)
+        sd.update(blk)
+        net = UNet3DVSRModel(init_weights=False, sample_size=8, block_out_channels=(C,), cross_attention_dim=1024,
+                             layers_per_block=1, down_block_types=("CrossAttnDownBlock3D",),
+                             up_block_types=("CrossAttnUpBlock3D",), only_cross_attention=(oc,))
+        net.load_state_dict({k: v.half() for k, v in sd.items()})
+        net = net.to("cuda", torch.float16)
+        b, _, f, h, w = c["x"].shape
+        y = ops.unet_transformer(net, "down_blocks.0.attentions.0", h16(to_rows(c["x"].float())), h16(c["ctx"]), b, f, h, w)
+        assert rel_l2(from_rows(y.float().cpu(), b, f, h, w), c["y"]) < TOL_BLOCK, (C, oc)

@@ -207,3 +207,21 @@ def test_vsr_resnet_block_3dcnn_direct_import():
         with torch.no_grad():
             ref = blk(x, temb)
         assert rel_l2(V.resnet_block_3dcnn(sd, "", x, temb), ref) < 1e-5
+
+
+@pytest.mark.parametrize("only_cross", [True, False])
+def test_vsr_transformer3d_matches_reference(only_cross):
+    """oracle/vsr_blocks.py against vsr/models/attention.py's Transformer3DModel (under the shim)."""
+    from oracle import vsr_blocks as V
+    m = refimport.load_vsr_blocks()                      # puts tests/refshim on sys.path
+    from rotary_embedding_torch import RotaryEmbedding
+    tr = m.attention.Transformer3DModel(8, 32, in_channels=256, num_layers=1, cross_attention_dim=128, norm_num_groups=32,
+                                        use_linear_projection=True, only_cross_attention=only_cross,
+                                        rotary_emb=RotaryEmbedding(32)).eval()
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in tr.state_dict().items()}, 7)
+    tr.load_state_dict(sd)
+    g = torch.Generator().manual_seed(2)
+    x, ctx = torch.randn(2, 256, 5, 4, 4, generator=g), torch.randn(2, 77, 128, generator=g)
+    with torch.no_grad():
+        ref = tr(x, encoder_hidden_states=ctx).sample
+    assert rel_l2(V.vsr_transformer3d(sd, "", x, ctx, 8, only_cross), ref) < 1e-5
