@@ -77,3 +77,64 @@ def resnet_block_3dcnn_no_temb(sd: SD, p: str, x, groups: int = 32, eps: float =
     h = F.silu(F.group_norm(h, groups, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps))
     h = temporal_conv(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"])
     return x + h
+
+
+# --------------------------------------------------------------------------- TemporalModule3D and the whole VSR UNet
+def spatial_resnet_block(sd: SD, p: str, x, temb, groups: int, eps: float):
+    """vsr ResnetBlock3D (vsr/models/resnet.py:118-217) = the base model's block; `eps` differs by call site."""
+    from . import unet_fp32 as O
+    cfg = O.UNetConfig(norm_groups=groups, norm_eps=eps)
+    return O.resnet_block(sd, p, x, temb, cfg)
+
+
+def temporal_module(sd: SD, p: str, x, temb, groups: int = 32):
+    """TemporalModule3D.forward (vsr/models/temporal_module.py:153-178) with attention_block_types ("", ""), no video
+    condition, use_scale_shift False: ResnetBlock3DCNN (5,1,1) -> ResnetBlock3D (both eps 1e-6, with temb) -> zero-initialised
+    1x1 shift conv -> input + shift."""
+    from . import unet_fp32 as O
+    h = resnet_block_3dcnn(sd, p + "resblocks_3d_t.", x, temb, groups)
+    h = spatial_resnet_block(sd, p + "resblocks_3d_s.", h, temb, groups, 1e-6)
+    return x + O.conv_frames(h, sd[p + "shift_conv.weight"], sd[p + "shift_conv.bias"], padding=0)
+
+
+def vsr_unet_forward(sd: SD, sample, low_res, timesteps, ctx, class_labels, block_out_channels=(256, 512, 512, 1024),
+                     attn_levels=(False, True, True, True), only_cross_attention=(True, True, True, False),
+                     layers_per_block: int = 2, heads: int = 8, groups: int = 32, eps: float = 1e-5):
+    """UNet3DVSRModel.forward (vsr/models/unet.py:408-600): sample [b,4,f,h,w] and low_res [b,3,f,h,w] are concatenated on
+    channels (:453); emb = time_embedding + class_embedding[noise level] (:489-505); a TemporalModule3D follows every down
+    block (after its downsampler, skips taken before it), the mid block and every up block (after its upsampler)."""
+    from . import unet_fp32 as O
+    x = torch.cat([sample, low_res], dim=1).float()
+    ucfg = O.UNetConfig(block_out_channels=tuple(block_out_channels), norm_groups=groups, norm_eps=eps, heads=heads)
+    t = torch.as_tensor(timesteps).reshape(-1).expand(x.shape[0])
+    emb = O.time_embedding(sd, t, ucfg) + sd["class_embedding.weight"][torch.as_tensor(class_labels).reshape(-1)]
+    ctx = ctx.float()
+    nlev = len(block_out_channels)
+    x = O.conv_frames(x, sd["conv_in.weight"], sd["conv_in.bias"])
+    skips = [x]
+    for lvl in range(nlev):
+        for j in range(layers_per_block):
+            x = O.resnet_block(sd, f"down_blocks.{lvl}.resnets.{j}.", x, emb, ucfg)
+            if attn_levels[lvl]:
+                x = vsr_transformer3d(sd, f"down_blocks.{lvl}.attentions.{j}.", x, ctx, heads, only_cross_attention[lvl], groups)
+            skips.append(x)
+        if lvl != nlev - 1:
+            x = O.downsample(sd, f"down_blocks.{lvl}.downsamplers.0.", x)
+            skips.append(x)
+        x = temporal_module(sd, f"down_temporal_blocks.{lvl}.", x, emb, groups)
+    x = O.resnet_block(sd, "mid_block.resnets.0.", x, emb, ucfg)
+    x = vsr_transformer3d(sd, "mid_block.attentions.0.", x, ctx, heads, False, groups)
+    x = O.resnet_block(sd, "mid_block.resnets.1.", x, emb, ucfg)
+    x = temporal_module(sd, "mid_temporal_block.", x, emb, groups)
+    for i in range(nlev):
+        lvl = nlev - 1 - i
+        for j in range(layers_per_block + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = O.resnet_block(sd, f"up_blocks.{i}.resnets.{j}.", x, emb, ucfg)
+            if attn_levels[lvl]:
+                x = vsr_transformer3d(sd, f"up_blocks.{i}.attentions.{j}.", x, ctx, heads, only_cross_attention[lvl], groups)
+        if i != nlev - 1:
+            x = O.upsample(sd, f"up_blocks.{i}.upsamplers.0.", x)
+        x = temporal_module(sd, f"up_temporal_blocks.{i}.", x, emb, groups)
+    x = F.silu(F.group_norm(x, groups, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps))
+    return O.conv_frames(x, sd["conv_out.weight"], sd["conv_out.bias"])

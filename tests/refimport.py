@@ -62,7 +62,7 @@ def load_interp_diffusion():
 
 
 def load_vsr_blocks():
-    """vsr/models/{resnet,attention}.py under the shim (the VSR UNet file itself needs torchvision, absent here)."""
+    """vsr/models/{resnet,attention,unet_blocks,diffusers_attention,temporal_module,unet}.py under the shim."""
     pkgname, root = "refmodels_vsr", "/root/reference/vsr/models"
     if f"{pkgname}.attention" in sys.modules:
         return sys.modules[pkgname]
@@ -71,10 +71,15 @@ def load_vsr_blocks():
     pkg = importlib.util.module_from_spec(importlib.machinery.ModuleSpec(pkgname, None, is_package=True))
     pkg.__path__ = [root]
     sys.modules[pkgname] = pkg
-    for name in ("resnet", "attention"):
+    for name in ("resnet", "attention", "unet_blocks", "diffusers_attention", "temporal_module", "unet"):
         spec = importlib.util.spec_from_file_location(f"{pkgname}.{name}", os.path.join(root, f"{name}.py"))
         mod = importlib.util.module_from_spec(spec)
         sys.modules[f"{pkgname}.{name}"] = mod
         spec.loader.exec_module(mod)
         setattr(pkg, name, mod)
     return pkg
+
+
+VSR_TEMPORAL_MODULE_CONFIG = dict(       # vsr/configs/unet_3d_config.json "temporal_module_config" (values, not code)
+    num_attention_layers=1, attention_block_types=["", ""], cross_frame_attention_mode="0_i-1_i", temporal_shift_fold_div=2,
+    temporal_shift_direction="right", use_dcn_warpping=False, use_deformable_conv=True, attention_dim_div=2)

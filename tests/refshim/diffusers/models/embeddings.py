@@ -34,3 +34,8 @@ class TimestepEmbedding(nn.Module):
 
     def forward(self, x):
         return self.linear_2(self.act(self.linear_1(x)))
+
+
+class ImagePositionalEmbeddings(nn.Module):   # symbol only: vsr/models/diffusers_attention.py imports it, the VSR path never builds it
+    def __init__(self, *a, **k):
+        raise NotImplementedError

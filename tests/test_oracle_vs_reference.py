@@ -225,3 +225,26 @@ def test_vsr_transformer3d_matches_reference(only_cross):
     with torch.no_grad():
         ref = tr(x, encoder_hidden_states=ctx).sample
     assert rel_l2(V.vsr_transformer3d(sd, "", x, ctx, 8, only_cross), ref) < 1e-5
+
+
+def test_vsr_unet_small_matches_reference():
+    """oracle.vsr_blocks.vsr_unet_forward against the imported vsr/models UNet3DVSRModel (temporal modules after every
+    block, class-embedded noise level, 4 + 3 input channels, only_cross_attention levels) at a small width."""
+    from oracle import vsr_blocks as V
+    m = refimport.load_vsr_blocks()
+    net = m.unet.UNet3DVSRModel(
+        sample_size=8, in_channels=7, out_channels=4, block_out_channels=(64, 128),
+        down_block_types=("DownBlock3D", "CrossAttnDownBlock3D"), up_block_types=("CrossAttnUpBlock3D", "UpBlock3D"),
+        only_cross_attention=(True, False), layers_per_block=1, cross_attention_dim=64, attention_head_dim=4,
+        use_linear_projection=True, num_class_embeds=1000, down_temporal_idx=(0, 1), mid_temporal=True,
+        up_temporal_idx=(0, 1), video_condition=False, temporal_module_config=refimport.VSR_TEMPORAL_MODULE_CONFIG).eval()
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 9)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(1)
+    x, lr = torch.randn(2, 4, 5, 8, 8, generator=g), torch.randn(2, 3, 5, 8, 8, generator=g)
+    ctx, labels = torch.randn(2, 77, 64, generator=g), torch.tensor([20, 250])
+    with torch.no_grad():
+        ref = net(x, torch.tensor(500), lr, encoder_hidden_states=ctx, class_labels=labels).sample
+    got = V.vsr_unet_forward(sd, x, lr, 500, ctx, labels, block_out_channels=(64, 128), attn_levels=(False, True),
+                             only_cross_attention=(True, False), layers_per_block=1, heads=4)
+    assert rel_l2(got, ref) < 1e-5
