@@ -186,6 +186,14 @@ typedef struct lavie_unet_config {
      *   only_cross_attention[l] : attn1 of level l attends to the text context instead of the frame (:465-490, 558-561) */
     int vsr_blocks;
     int only_cross_attention[LAVIE_MAX_LEVELS];
+    /* UNet3DVSRModel (vsr/models/unet.py:100-600):
+     *   vsr_temporal_modules : a TemporalModule3D (ResnetBlock3DCNN (5,1,1) -> ResnetBlock3D -> zero-initialised 1x1 shift
+     *                          conv, residual; temporal_module.py:65-178) after every down block, the mid block and every
+     *                          up block (down_temporal_idx / mid_temporal / up_temporal_idx = all levels)
+     *   num_class_embeds     : > 0: emb = time_embedding + class_embedding[noise level] (:176-177, 494-505); the forward
+     *                          entry is then lavie_unet_forward_labels */
+    int vsr_temporal_modules;
+    int num_class_embeds;
 } lavie_unet_config;
 
 int lavie_unet_create(const lavie_unet_config* cfg, lavie_unet_t* out);
@@ -209,6 +217,10 @@ long long lavie_unet_workspace_bytes(lavie_unet_t h);
  * ctx [B, ctx_len, cross_attention_dim] fp16  ->  out [B, Cout, F, H, W] fp16. */
 int lavie_unet_forward(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx, void* out, int B,
                        int F, int H, int W, int ctx_len, void* stream);
+
+/* Same for a model with num_class_embeds > 0: class_labels_host[B] (host ints, the VSR noise level per video). */
+int lavie_unet_forward_labels(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx,
+                              const int* class_labels_host, void* out, int B, int F, int H, int W, int ctx_len, void* stream);
 
 /* Finer engine seams for parity tests (same packed weights as the whole model):
  * ResnetBlock3D.forward (resnet.py:177-207) and Transformer3DModel.forward (attention.py:358-407)

@@ -22,6 +22,7 @@ class UNetConfigC(C.Structure):
         ("norm_eps", c_float), ("rotary_dim", c_int), ("rel_buckets", c_int), ("rel_max_distance", c_int),
         ("sparse_causal_attn1", c_int), ("temporal_plain", c_int), ("ff_before_temporal", c_int),
         ("vsr_blocks", c_int), ("only_cross_attention", c_int * MAX_LEVELS),
+        ("vsr_temporal_modules", c_int), ("num_class_embeds", c_int),
     ]
 
 
@@ -77,6 +78,8 @@ SIGNATURES = {
     "lavie_unet_workspace_bytes": (c_ll, [c_void_p]),
     "lavie_unet_forward": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p]),
+    "lavie_unet_forward_labels": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, C.POINTER(c_int), c_void_p, c_int, c_int,
+                                           c_int, c_int, c_int, c_void_p]),
     "lavie_unet_resnet_forward": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_void_p, c_int, c_float_p, c_void_p, c_int,
                                            c_int, c_int, c_int, c_void_p]),
     "lavie_unet_transformer_forward": (c_int, [c_void_p, c_char_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

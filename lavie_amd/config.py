@@ -27,6 +27,8 @@ class UNetConfig:
     # Block variant of the VSR stage's UNet3DVSRModel (vsr/models/attention.py:314-594)
     vsr_blocks: bool = False             # resblock_temporal in front, attn_temporal / norm_temporal names, Linear proj_in/out
     only_cross_attention: Tuple[bool, ...] = ()      # per level: attn1 attends to the text context
+    vsr_temporal_modules: bool = False   # TemporalModule3D after every down / mid / up block (vsr/models/unet.py:238-330)
+    num_class_embeds: int = 0            # > 0: nn.Embedding noise-level table added to the time embedding (:176-177)
 
     @property
     def time_embed_dim(self) -> int:
@@ -49,6 +51,10 @@ class UNetConfig:
 
 
 BASE_CONFIG = UNetConfig()
+# vsr/configs/unet_3d_config.json (UNet3DVSRModel): the SD x4-upscaler UNet with temporal modules; 4 noisy + 3 low-res channels
+VSR_CONFIG = UNetConfig(sample_size=128, in_channels=7, block_out_channels=(256, 512, 512, 1024), cross_attention_dim=1024,
+                        attn_levels=(False, True, True, True), vsr_blocks=True, only_cross_attention=(True, True, True, False),
+                        vsr_temporal_modules=True, num_class_embeds=1000)
 # `from_pretrained_2d(..., use_concat=True, copy_no_mask=True)` of the interpolation stage (interpolation/models/unet.py:
 # 477-506, interpolation/configs/sample.yaml): noisy latent || copied low-frame-rate latent on 8 input channels
 INTERPOLATION_CONFIG = UNetConfig(in_channels=8, sparse_causal_attn1=True, temporal_plain=True, ff_before_temporal=True)

@@ -283,7 +283,13 @@ long long lavie_unet_workspace_bytes(lavie_unet_t h) { return h ? h->net.workspa
 int lavie_unet_forward(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx, void* out, int B,
                        int F, int Hh, int W, int ctx_len, void* stream) {
     LAVIE_CHECK(h, "forward: null handle");
-    return h->net.forward(H(sample), timesteps, H(ctx), H(out), B, F, Hh, W, ctx_len, S(stream));
+    return h->net.forward(H(sample), timesteps, H(ctx), H(out), B, F, Hh, W, ctx_len, S(stream), nullptr);
+}
+
+int lavie_unet_forward_labels(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx,
+                              const int* class_labels_host, void* out, int B, int F, int Hh, int W, int ctx_len, void* stream) {
+    LAVIE_CHECK(h && class_labels_host, "forward_labels: null handle / labels");
+    return h->net.forward(H(sample), timesteps, H(ctx), H(out), B, F, Hh, W, ctx_len, S(stream), class_labels_host);
 }
 
 int lavie_unet_resnet_forward(lavie_unet_t h, const char* prefix, const void* x1, int C1, const void* x2, int C2,

@@ -238,6 +238,27 @@ int launch_conv_out(const half_t* x, const half_t* wp, const float* bias, half_t
     return 0;
 }
 
+// ------------------------------------------------------------------ class embedding (VSR noise level)
+// emb[b, :] = silu(emb[b, :] + table[label_b, :]) (vsr/models/unet.py:494-505; the SiLU is the one every consumer of emb
+// applies first, resnet.py:186).  Labels travel by value (B <= 8).
+struct ClassLabels { int v[8]; };
+__global__ void add_class_emb_silu_kernel(float* __restrict__ emb, const half_t* __restrict__ table, ClassLabels lab, int B, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, n = i - b * N;
+    const float x = emb[i] + (float)table[(size_t)lab.v[b] * N + n];
+    emb[i] = silu_f(x);
+}
+
+int launch_add_class_emb_silu(float* emb, const half_t* table, const int* labels_host, int B, int N, hipStream_t stream) {
+    LAVIE_CHECK(B >= 1 && B <= 8, "class embedding: batch %d unsupported (1..8)", B);
+    ClassLabels lab;
+    for (int b = 0; b < 8; ++b) lab.v[b] = b < B ? labels_host[b] : 0;
+    hipLaunchKernelGGL(add_class_emb_silu_kernel, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, stream, emb, table, lab, B, N);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ CFG + DDPM step
 // pipeline_videogen.py:679-683 with the scheduler arithmetic of oracle/ddpm.py (diffusers DDPMScheduler.step).
 __global__ void cfg_ddpm_step_kernel(const half_t* __restrict__ eps2, float* __restrict__ x,

@@ -160,8 +160,32 @@ void UNet::build_param_list() {
         t.attn1_cross = cross1;
         transformers_.push_back(t);
     };
+    auto temporal_module = [&](const std::string& p, int ch) {
+        TemporalModuleW m;
+        m.prefix = p; m.C = ch;
+        const std::string t = p + ".resblocks_3d_t", sp = p + ".resblocks_3d_s";
+        affine(t + ".norm1", ch);
+        conv_t(t + ".conv1", ch, ch, 5);
+        lin(t + ".time_emb_proj", temb, ch, true);
+        affine(t + ".norm2", ch);
+        conv_t(t + ".conv2", ch, ch, 3);
+        m.t_temb_off = temb_total;
+        temb_total += ch;
+        affine(sp + ".norm1", ch);
+        conv(sp + ".conv1", ch, ch, 3);
+        lin(sp + ".time_emb_proj", temb, ch, true);
+        affine(sp + ".norm2", ch);
+        conv(sp + ".conv2", ch, ch, 3);
+        m.s.prefix = sp; m.s.cin = ch; m.s.cout = ch; m.s.shortcut = false; m.s.temb_off = temb_total; m.s.eps = 1e-6f;
+        temb_total += ch;
+        conv(p + ".shift_conv", ch, ch, 1);
+        tmods_.push_back(m);
+    };
+    const bool tmod = c.vsr_temporal_modules != 0;
     const int* widths = c.block_out_channels;
     const int L = c.num_levels;
+    if (c.num_class_embeds > 0) add("class_embedding.weight", {c.num_class_embeds, temb});
+    if (c.vsr_blocks && !c.temporal_plain) add("temporal_rotary_emb.freqs", {c.rotary_dim / 2});   // accepted, ignored
     conv("conv_in", c.in_channels, widths[0], 3);
     lin("time_embedding.linear_1", widths[0], temb, true);
     lin("time_embedding.linear_2", temb, temb, true);
@@ -179,10 +203,12 @@ void UNet::build_param_list() {
             conv("down_blocks." + std::to_string(l) + ".downsamplers.0.conv", cur, cur, 3);
             skips.push_back(cur);
         }
+        if (tmod) temporal_module("down_temporal_blocks." + std::to_string(l), cur);
     }
     resnet("mid_block.resnets.0", cur, cur);
     transformer("mid_block.attentions.0", cur, -1);      // the mid block always self-attends (vsr/models/unet.py:248-270)
     resnet("mid_block.resnets.1", cur, cur);
+    if (tmod) temporal_module("mid_temporal_block", cur);
     for (int i = 0; i < L; ++i) {
         const int l = L - 1 - i;
         const std::string p = "up_blocks." + std::to_string(i);
@@ -194,6 +220,7 @@ void UNet::build_param_list() {
             if (c.attn_levels[l]) transformer(p + ".attentions." + std::to_string(j), cur, l);
         }
         if (i + 1 < L) conv(p + ".upsamplers.0.conv", cur, cur, 3);
+        if (tmod) temporal_module("up_temporal_blocks." + std::to_string(i), cur);
     }
     affine("conv_norm_out", widths[0]);
     conv("conv_out", widths[0], c.out_channels, 3);
@@ -442,6 +469,24 @@ int UNet::finalize(hipStream_t s) {
     WALLOC(tproj_.b, float, tproj_.N);
     for (ResnetW& r : resnets_) RUN(pack_resnet(&r, s));
     for (TransformerW& t : transformers_) RUN(pack_transformer(&t, s));
+    for (TemporalModuleW& m : tmods_) {
+        RUN(pack_temporal_res(m.prefix + ".resblocks_3d_t", m.C, 5, &m.t, s));
+        const half_t* wt = given(m.prefix + ".resblocks_3d_t.time_emb_proj.weight");
+        const half_t* bt = given(m.prefix + ".resblocks_3d_t.time_emb_proj.bias");
+        NEED(wt, m.prefix + ".resblocks_3d_t.time_emb_proj.weight"); NEED(bt, m.prefix + ".resblocks_3d_t.time_emb_proj.bias");
+        LAVIE_HIP(hipMemcpyAsync(tproj_.w + (size_t)m.t_temb_off * tproj_.K, wt, (size_t)m.C * tproj_.K * sizeof(half_t),
+                                 hipMemcpyDeviceToDevice, s));
+        RUN(launch_f16_to_f32(bt, tproj_.b + m.t_temb_off, m.C, s));
+        RUN(pack_resnet(&m.s, s));
+        RUN(pack_linear(m.prefix + ".shift_conv", m.C, m.C, true, &m.shift, s));
+    }
+    if (c.num_class_embeds > 0) {
+        const half_t* e = given("class_embedding.weight");
+        NEED(e, std::string("class_embedding.weight"));
+        const size_t n = (size_t)c.num_class_embeds * C0 * 4;
+        WALLOC(class_emb_, half_t, n);
+        LAVIE_HIP(hipMemcpyAsync(class_emb_, e, n * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+    }
     const int L = c.num_levels;
     downs_.resize(L > 1 ? L - 1 : 0);
     ups_.resize(L > 1 ? L - 1 : 0);
@@ -499,6 +544,7 @@ struct FwdCtx {
     bool dry;               // plan only: allocate, launch nothing
     int B, F, ctx_len;
     float* gn_ws;           // GroupNorm scratch, gn_workspace_floats(B*F, groups) floats
+    const int* labels = nullptr;   // VSR noise level per video (host), num_class_embeds > 0
 };
 
 #define LAUNCH(expr)              \
@@ -621,18 +667,36 @@ static int tconv(FwdCtx& c, const half_t* x, int C, const half_t* W, const float
     return rc;
 }
 
-// ResnetBlock3DCNN without time embedding, in place on x (vsr/models/resnet.py:283-315; attention.py:350, 395-398):
-// GroupNorm statistics span the whole video (5-D input), eps 1e-6.
-int UNet::run_temporal_res(FwdCtx& c, const TemporalResW& r, half_t* x, int C, int D) {
+// ResnetBlock3DCNN (vsr/models/resnet.py:283-315): y = x + conv2(silu(gn(conv1(silu(gn(x))) + temb))); GroupNorm statistics
+// span the whole video (5-D input), eps 1e-6; bias2 = the block's rows of the fused time-embedding projection or nullptr
+// (attention.py:350: temb_channels=None).  y may alias x.
+int UNet::run_temporal_res(FwdCtx& c, const TemporalResW& r, const half_t* x, half_t* y, int C, int D, const float* bias2,
+                           int ldb2) {
     const size_t M = (size_t)c.B * c.F * D;
     const int P = c.F * D;
     const size_t mark = c.ws->mark();
     WS(nrm, half_t, M * C);
     WS(h1, half_t, M * C);
     LAUNCH(launch_group_norm(x, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n1.g, r.n1.b, 1e-6f, true, c.gn_ws, nrm, c.s));
-    RUN(tconv(c, nrm, C, r.w1, r.b1, nullptr, 0, nullptr, h1, D, C, r.taps1, zero_page_));
+    RUN(tconv(c, nrm, C, r.w1, r.b1, bias2, ldb2, nullptr, h1, D, C, r.taps1, zero_page_));
     LAUNCH(launch_group_norm(h1, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n2.g, r.n2.b, 1e-6f, true, c.gn_ws, nrm, c.s));
-    RUN(tconv(c, nrm, C, r.w2, r.b2, nullptr, 0, x, x, D, C, 3, zero_page_));
+    RUN(tconv(c, nrm, C, r.w2, r.b2, nullptr, 0, x, y, D, C, 3, zero_page_));
+    c.ws->release(mark);
+    return 0;
+}
+
+// TemporalModule3D.forward (vsr/models/temporal_module.py:153-178): y = x + shift_conv(resblocks_3d_s(resblocks_3d_t(x))).
+// y must not alias x when x is still referenced as a skip tensor.
+int UNet::run_temporal_module(FwdCtx& c, const TemporalModuleW& m, const half_t* x, half_t* y, const float* tproj,
+                              int ld_tproj, int H, int W) {
+    const int C = m.C, D = H * W;
+    const size_t M = (size_t)c.B * c.F * D;
+    const size_t mark = c.ws->mark();
+    WS(h1, half_t, M * C);
+    WS(h2, half_t, M * C);
+    RUN(run_temporal_res(c, m.t, x, h1, C, D, tproj + m.t_temb_off, ld_tproj));
+    RUN(run_resnet(c, m.s, h1, C, nullptr, 0, tproj + m.s.temb_off, ld_tproj, h2, H, W));
+    RUN(linear(c, h2, C, m.shift.w, m.shift.b, C, C, x, y, C, (int)M));
     c.ws->release(mark);
     return 0;
 }
@@ -648,14 +712,15 @@ int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, cons
     WS(nrm, half_t, M * r.cin);
     WS(h1, half_t, M * r.cout);
     WS(n2, half_t, M * r.cout);
-    LAUNCH(launch_group_norm(x1, C1, x2, C2, c.B, P, G, r.n1.g, r.n1.b, cfg_.norm_eps, true, c.gn_ws, nrm, c.s));
+    const float eps = r.eps > 0.f ? r.eps : cfg_.norm_eps;
+    LAUNCH(launch_group_norm(x1, C1, x2, C2, c.B, P, G, r.n1.g, r.n1.b, eps, true, c.gn_ws, nrm, c.s));
     {
         const half_t* src[1] = {nrm};
         const int srcC[1] = {r.cin};
         RUN(conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, r.w1, 9 * r.cin, r.b1, tproj, ld_tproj, P, nullptr, h1, NI, H, W,
                     r.cout, 1, 0, zero_page_));
     }
-    LAUNCH(launch_group_norm(h1, r.cout, nullptr, 0, c.B, P, G, r.n2.g, r.n2.b, cfg_.norm_eps, true, c.gn_ws, n2, c.s));
+    LAUNCH(launch_group_norm(h1, r.cout, nullptr, 0, c.B, P, G, r.n2.g, r.n2.b, eps, true, c.gn_ws, n2, c.s));
     {
         const half_t* src[1] = {n2};
         const int srcC[1] = {r.cout};
@@ -684,7 +749,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     const size_t ti = &t - transformers_.data();
 
     // VSR: ResnetBlock3DCNN (3,1,1) on the block input, before the residual is taken (vsr/models/attention.py:395-400)
-    if (t.tres.present) RUN(run_temporal_res(c, t.tres, x, C, D));
+    if (t.tres.present) RUN(run_temporal_res(c, t.tres, x, x, C, D, nullptr, 0));
     // per-frame GroupNorm (eps 1e-6) + 1x1 proj_in (attention.py:369-373)
     LAUNCH(launch_group_norm(x, C, nullptr, 0, NI, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s));
     // LayerNorm folding: the GEMM that produces the residual stream `tx` also emits per-row (sum, sum^2) partials of
@@ -842,7 +907,18 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
     LAUNCH(launch_gemv(tsin, time1_.w, time1_.b, e1, c.B, temb, C0, 0, 1, c.s));
     // `emb` only ever reaches the resnets through SiLU (resnet.py:186): apply it once here instead of once per
     // output feature inside the stacked projection
-    LAUNCH(launch_gemv(e1, time2_.w, time2_.b, emb, c.B, temb, temb, 0, 1, c.s));
+    if (cfg.num_class_embeds > 0) {
+        // emb = time_embedding + class_embedding[noise level] (vsr/models/unet.py:494-505), then the consumers' SiLU
+        LAUNCH(launch_gemv(e1, time2_.w, time2_.b, emb, c.B, temb, temb, 0, 0, c.s));
+        if (!c.dry) {
+            LAVIE_CHECK(c.labels != nullptr, "forward: this model has a class embedding: call lavie_unet_forward_labels");
+            for (int b = 0; b < c.B; ++b)
+                LAVIE_CHECK(c.labels[b] >= 0 && c.labels[b] < cfg.num_class_embeds, "forward: class label %d out of range", c.labels[b]);
+            RUN(launch_add_class_emb_silu(emb, class_emb_, c.labels, c.B, temb, c.s));
+        }
+    } else {
+        LAUNCH(launch_gemv(e1, time2_.w, time2_.b, emb, c.B, temb, temb, 0, 1, c.s));
+    }
     LAUNCH(launch_gemv(emb, tproj_.w, tproj_.b, tproj, c.B, tproj_.N, temb, 0, 0, c.s));
 
     std::vector<int> Hs(L), Ws(L);
@@ -855,7 +931,8 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
 
     struct Skip { half_t* p; int C; };
     std::vector<Skip> skips;
-    size_t ri = 0, ti = 0;
+    size_t ri = 0, ti = 0, mi = 0;
+    const bool tmod = cfg.vsr_temporal_modules != 0;
 
     WS(x0, half_t, rows(0) * C0);
     LAUNCH(launch_conv_in(sample, conv_in_w_, conv_in_b_, x0, c.B, cfg.in_channels, c.F, Hs[0], Ws[0], C0, c.s));
@@ -878,6 +955,12 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
             x = y;
             skips.push_back({x, C});
         }
+        if (tmod) {       // after the downsampler, into a NEW buffer: x itself stays alive as a skip (vsr/models/unet.py:523-533)
+            const int ll = l + 1 < L ? l + 1 : l;
+            WS(yt, half_t, rows(ll) * C);
+            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[ll], Ws[ll]));
+            x = yt;
+        }
     }
     {
         const int l = L - 1;
@@ -890,6 +973,11 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
         WS(y1, half_t, rows(l) * r1.cout);
         RUN(run_resnet(c, r1, x, C, nullptr, 0, tproj + r1.temb_off, tproj_.N, y1, Hs[l], Ws[l]));
         x = y1; C = r1.cout;
+        if (tmod) {
+            WS(yt, half_t, rows(l) * C);
+            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[l], Ws[l]));
+            x = yt;
+        }
     }
     for (int i = 0; i < L; ++i) {
         const int l = L - 1 - i;
@@ -906,6 +994,12 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
             WS(y, half_t, rows(l - 1) * C);
             RUN(run_conv(c, x, C, ups_[i], y, Hs[l], Ws[l], 1, 1));
             x = y;
+        }
+        if (tmod) {       // after the upsampler (vsr/models/unet.py:575-590)
+            const int ll = i + 1 < L ? l - 1 : l;
+            WS(yt, half_t, rows(ll) * C);
+            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[ll], Ws[ll]));
+            x = yt;
         }
     }
     // conv_norm_out + SiLU + conv_out (unet.py:504-506), back to the caller's NCFHW layout
@@ -942,7 +1036,7 @@ int UNet::prepare(int B, int F, int H, int W, int ctx_len) {
 }
 
 int UNet::forward(const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out, int B, int F, int H, int W,
-                  int ctx_len, hipStream_t stream) {
+                  int ctx_len, hipStream_t stream, const int* class_labels_host) {
     LAVIE_CHECK(finalized_, "forward: call lavie_unet_finalize first");
     LAVIE_CHECK(sample && timesteps && ctx && out, "forward: null tensor");
     RUN(check_shape(cfg_, B, F, H, W, ctx_len));
@@ -950,6 +1044,7 @@ int UNet::forward(const half_t* sample, const float* timesteps, const half_t* ct
     RUN(ensure_tables(F, stream));
     ws_.release(0);
     FwdCtx c{stream, &ws_, false, B, F, ctx_len, nullptr};
+    c.labels = class_labels_host;
     prep_H_ = H; prep_W_ = W;
     return run(c, sample, timesteps, ctx, out);
 }

@@ -49,6 +49,7 @@ struct ResnetW {
     half_t* w2 = nullptr; float* b2 = nullptr;      // [cout][9*cout (+ cin)] ; b2 = conv2.bias (+ shortcut.bias)
     int ldw2 = 0;
     int temb_off = 0;                               // column of this block inside the fused time_emb_proj output
+    float eps = 0.f;                                // GroupNorm eps; 0 = the model's norm_eps
 };
 
 // ResnetBlock3DCNN (vsr/models/resnet.py:220-315): GroupNorm + SiLU -> (T,1,1) conv -> GroupNorm + SiLU -> (3,1,1) conv
@@ -84,6 +85,16 @@ struct TransformerW {
 
 struct SamplerW { half_t* w = nullptr; float* b = nullptr; int C = 0; };
 
+// TemporalModule3D (vsr/models/temporal_module.py:65-178): ResnetBlock3DCNN (5,1,1) -> ResnetBlock3D -> 1x1 shift conv
+struct TemporalModuleW {
+    std::string prefix;
+    int C = 0;
+    TemporalResW t;
+    int t_temb_off = 0;                             // column of resblocks_3d_t.time_emb_proj inside the fused projection
+    ResnetW s;
+    LinW shift;
+};
+
 struct FwdCtx;   // per-call state (engine.cpp)
 
 class UNet {
@@ -96,7 +107,7 @@ public:
     int finalize(hipStream_t stream);
     int prepare(int B, int F, int H, int W, int ctx_len);
     int forward(const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out, int B, int F, int H, int W,
-                int ctx_len, hipStream_t stream);
+                int ctx_len, hipStream_t stream, const int* class_labels_host);
     int resnet_forward(const char* prefix, const half_t* x1, int C1, const half_t* x2, int C2, const float* temb, half_t* y,
                        int B, int F, int H, int W, hipStream_t stream);
     int transformer_forward(const char* prefix, half_t* x, const half_t* ctx, int B, int F, int H, int W, int ctx_len,
@@ -113,7 +124,9 @@ private:
     int pack_resnet(ResnetW* r, hipStream_t s);
     int pack_transformer(TransformerW* t, hipStream_t s);
     int pack_temporal_res(const std::string& prefix, int C, int taps1, TemporalResW* out, hipStream_t s);
-    int run_temporal_res(FwdCtx& c, const TemporalResW& r, half_t* x, int C, int D);
+    int run_temporal_res(FwdCtx& c, const TemporalResW& r, const half_t* x, half_t* y, int C, int D, const float* bias2, int ldb2);
+    int run_temporal_module(FwdCtx& c, const TemporalModuleW& m, const half_t* x, half_t* y, const float* tproj, int ld_tproj,
+                            int H, int W);
     int pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s);
     int ensure_tables(int F, hipStream_t s);
 
@@ -139,6 +152,8 @@ private:
     std::vector<ResnetW> resnets_;                  // execution order
     std::vector<TransformerW> transformers_;
     std::vector<SamplerW> downs_, ups_;
+    std::vector<TemporalModuleW> tmods_;            // VSR: down 0..L-1, mid, up 0..L-1
+    half_t* class_emb_ = nullptr;                   // [num_class_embeds][time_embed_dim] fp16 (state-dict tensor)
     half_t* zero_page_ = nullptr;
     // per-F tables
     int tables_F_ = 0;

@@ -77,10 +77,27 @@ def _transformer(prefix: str, c: int, cfg: UNetConfig, level: int = -1) -> Itera
     yield from (_linear(prefix + ".proj_out", c, c) if vsr else _conv(prefix + ".proj_out", c, c, 1))
 
 
+def _temporal_module(prefix: str, c: int, temb: int) -> Iterator[Tuple[str, Shape]]:
+    """TemporalModule3D (vsr/models/temporal_module.py:65-150) with attention_block_types ("", "")."""
+    t, s = prefix + ".resblocks_3d_t", prefix + ".resblocks_3d_s"
+    yield from _affine(t + ".norm1", c)
+    yield from _temporal_conv(t + ".conv1", c, c, 5)
+    yield from _linear(t + ".time_emb_proj", temb, c)
+    yield from _affine(t + ".norm2", c)
+    yield from _temporal_conv(t + ".conv2", c, c, 3)
+    yield from _resnet(s, c, c, temb)
+    yield from _conv(prefix + ".shift_conv", c, c, 1)
+
+
 def iter_params(cfg: UNetConfig = BASE_CONFIG) -> Iterator[Tuple[str, Shape]]:
     widths = cfg.block_out_channels
     temb = cfg.time_embed_dim
     levels = len(widths)
+    tmod = cfg.vsr_temporal_modules
+    if cfg.num_class_embeds:
+        yield "class_embedding.weight", (cfg.num_class_embeds, temb)
+    if cfg.vsr_blocks and not cfg.temporal_plain:
+        yield "temporal_rotary_emb.freqs", (cfg.rotary_dim // 2,)        # the shared RotaryEmbedding (vsr/models/unet.py:206)
     yield from _conv("conv_in", cfg.in_channels, widths[0], 3)
     yield from _linear("time_embedding.linear_1", widths[0], temb)
     yield from _linear("time_embedding.linear_2", temb, temb)
@@ -97,10 +114,14 @@ def iter_params(cfg: UNetConfig = BASE_CONFIG) -> Iterator[Tuple[str, Shape]]:
         if lvl + 1 < levels:
             yield from _conv(f"down_blocks.{lvl}.downsamplers.0.conv", cur, cur, 3)
             skips.append(cur)
+        if tmod:
+            yield from _temporal_module(f"down_temporal_blocks.{lvl}", cur, temb)
 
     yield from _resnet("mid_block.resnets.0", cur, cur, temb)
     yield from _transformer("mid_block.attentions.0", cur, cfg)
     yield from _resnet("mid_block.resnets.1", cur, cur, temb)
+    if tmod:
+        yield from _temporal_module("mid_temporal_block", cur, temb)
 
     for i in range(levels):
         lvl = levels - 1 - i
@@ -111,6 +132,8 @@ def iter_params(cfg: UNetConfig = BASE_CONFIG) -> Iterator[Tuple[str, Shape]]:
                 yield from _transformer(f"up_blocks.{i}.attentions.{j}", cur, cfg, lvl)
         if i + 1 < levels:
             yield from _conv(f"up_blocks.{i}.upsamplers.0.conv", cur, cur, 3)
+        if tmod:
+            yield from _temporal_module(f"up_temporal_blocks.{i}", cur, temb)
 
     yield from _affine("conv_norm_out", widths[0])
     yield from _conv("conv_out", widths[0], cfg.out_channels, 3)

@@ -121,7 +121,7 @@ class UNet3DConditionModel(nn.Module):
 
         # parameters under the reference's names; values follow the reference constructor's defaults
         for name, shape in spec.iter_params(self.cfg):
-            if name.endswith("rotary_emb.freqs"):
+            if name.endswith("rotary_emb.freqs"):       # incl. the VSR model's shared `temporal_rotary_emb.freqs`
                 p = nn.Parameter(rotary_freqs(self.cfg.rotary_dim), requires_grad=False)
             else:
                 p = nn.Parameter(torch.empty(shape), requires_grad=False)
@@ -200,6 +200,7 @@ class UNet3DConditionModel(nn.Module):
         c.vsr_blocks = int(cfg.vsr_blocks)
         for i, v in enumerate(cfg.only_cross_attention):
             c.only_cross_attention[i] = int(v)
+        c.vsr_temporal_modules, c.num_class_embeds = int(cfg.vsr_temporal_modules), int(cfg.num_class_embeds)
         return c
 
     def _ensure_engine(self):
@@ -219,8 +220,10 @@ class UNet3DConditionModel(nn.Module):
             _lib.check(lib.lavie_unet_create(ctypes.byref(cfg_c), ctypes.byref(handle)), "lavie_unet_create")
             try:
                 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                keep = []            # tensors made for the engine (contiguous / padded copies) stay alive until finalize
                 for name, p in self.named_parameters():
-                    t = p.data if p.data.is_contiguous() else p.data.contiguous()
+                    t = self._engine_tensor(name, p.data if p.data.is_contiguous() else p.data.contiguous())
+                    keep.append(t)
                     _lib.check(lib.lavie_unet_set_param(handle, name.encode(), ctypes.c_void_p(t.data_ptr()), t.numel()),
                                f"lavie_unet_set_param({name})")
                 _lib.check(lib.lavie_unet_finalize(handle, stream), "lavie_unet_finalize")
@@ -231,6 +234,10 @@ class UNet3DConditionModel(nn.Module):
         self.__dict__["_engine"] = handle
         self.__dict__["_engine_key"] = key
         return handle
+
+    def _engine_tensor(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        """Hook: the tensor handed to the engine for state-dict entry `name` (identity here)."""
+        return t
 
     def refresh_engine(self):
         """Re-packs the weights after parameters were modified in place."""

@@ -62,6 +62,20 @@ def main():
                           y=tr(x, encoder_hidden_states=ctx).sample))
     save("vsr_transformer3d.pt", dict(cases=cases))
 
+    # whole UNet3DVSRModel at full width (vsr/configs/unet_3d_config.json: 691 M parameters), 8x8, F = 5, B = 2, two noise levels
+    import refbuild
+    from lavie_amd import spec
+    from lavie_amd.config import VSR_CONFIG
+    seed = 6
+    net = refbuild.reference_vsr_unet(VSR_CONFIG)
+    net.load_state_dict(synth16(spec.param_shapes(VSR_CONFIG), seed))
+    x = q16(torch.randn(2, 4, 5, 8, 8, generator=g))
+    low = q16(torch.randn(2, 3, 5, 8, 8, generator=g))
+    ctx = q16(torch.randn(2, 77, 1024, generator=g))
+    labels = torch.tensor([20, 250])
+    outs = {t: net(x, torch.tensor(t), low, encoder_hidden_states=ctx, class_labels=labels).sample for t in (900, 20)}
+    save("vsr_unet_full_8x8.pt", dict(seed=seed, x=x.half(), low_res=low.half(), ctx=ctx.half(), labels=labels, y=outs))
+
 
 if __name__ == "__main__":
     main()

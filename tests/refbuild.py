@@ -49,3 +49,22 @@ def reference_interpolation_unet(cfg: UNetConfig, seed: int):
             down_block_types=tuple("CrossAttnDownBlock3D" if a else "DownBlock3D" for a in cfg.attn_levels),
             up_block_types=tuple("CrossAttnUpBlock3D" if a else "UpBlock3D" for a in reversed(cfg.attn_levels)))
     return net.eval()
+
+
+def reference_vsr_unet(cfg: UNetConfig):
+    """vsr/models/unet.py's UNet3DVSRModel as vsr/configs/unet_3d_config.json configures it (temporal modules on every level,
+    class-embedded noise level, no video condition), weights left uninitialised for the caller to load."""
+    m = refimport.load_vsr_blocks()
+    levels = len(cfg.block_out_channels)
+    idx = tuple(range(levels)) if cfg.vsr_temporal_modules else ()
+    with _no_init():
+        net = m.unet.UNet3DVSRModel(
+            sample_size=cfg.sample_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+            block_out_channels=cfg.block_out_channels, layers_per_block=cfg.layers_per_block,
+            down_block_types=tuple("CrossAttnDownBlock3D" if a else "DownBlock3D" for a in cfg.attn_levels),
+            up_block_types=tuple("CrossAttnUpBlock3D" if a else "UpBlock3D" for a in reversed(cfg.attn_levels)),
+            only_cross_attention=tuple(cfg.only_cross_attention), cross_attention_dim=cfg.cross_attention_dim,
+            attention_head_dim=cfg.heads, norm_num_groups=cfg.norm_groups, norm_eps=cfg.norm_eps, use_linear_projection=True,
+            num_class_embeds=cfg.num_class_embeds or None, down_temporal_idx=idx, mid_temporal=cfg.vsr_temporal_modules,
+            up_temporal_idx=idx, video_condition=False, temporal_module_config=refimport.VSR_TEMPORAL_MODULE_CONFIG)
+    return net.eval()

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import golden_util as G
-from gpu_util import TOL_BLOCK, TOL_OP, f32, h16, rel_l2
+from gpu_util import TOL_BLOCK, TOL_OP, TOL_UNET, f32, h16, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -70,17 +70,74 @@ def test_vsr_transformer_golden():
     from lavie_amd.vsr import UNet3DVSRModel
     for c in G.load("vsr_transformer3d.pt")["cases"]:
         C, oc = c["c"], c["only_cross"]
-        cfg = UNetConfig(block_out_channels=(C,), attn_levels=(True,), layers_per_block=1, cross_attention_dim=1024,
-                         vsr_blocks=True, only_cross_attention=(oc,))
+        cfg = UNetConfig(in_channels=7, block_out_channels=(C,), attn_levels=(True,), layers_per_block=1,
+                         cross_attention_dim=1024, vsr_blocks=True, only_cross_attention=(oc,))
         sd = G.synth16(spec.param_shapes(cfg), 5)
         blk = G.synth16(c["shapes"], c["seed"], "down_blocks.0.attentions.0.")
         assert set(blk) <= set(sd), set(blk) - set(sd)
         sd.update(blk)
         net = UNet3DVSRModel(init_weights=False, sample_size=8, block_out_channels=(C,), cross_attention_dim=1024,
                              layers_per_block=1, down_block_types=("CrossAttnDownBlock3D",),
-                             up_block_types=("CrossAttnUpBlock3D",), only_cross_attention=(oc,))
+                             up_block_types=("CrossAttnUpBlock3D",), only_cross_attention=(oc,), num_class_embeds=None,
+                             down_temporal_idx=(), mid_temporal=False, up_temporal_idx=())
         net.load_state_dict({k: v.half() for k, v in sd.items()})
         net = net.to("cuda", torch.float16)
         b, _, f, h, w = c["x"].shape
         y = ops.unet_transformer(net, "down_blocks.0.attentions.0", h16(to_rows(c["x"].float())), h16(c["ctx"]), b, f, h, w)
         assert rel_l2(from_rows(y.float().cpu(), b, f, h, w), c["y"]) < TOL_BLOCK, (C, oc)
+
+
+SMALL_VSR = dict(sample_size=8, block_out_channels=(256, 512), down_block_types=("DownBlock3D", "CrossAttnDownBlock3D"),
+                 up_block_types=("CrossAttnUpBlock3D", "UpBlock3D"), only_cross_attention=(True, False), layers_per_block=1,
+                 cross_attention_dim=128, attention_head_dim=8, down_temporal_idx=(0, 1), mid_temporal=True,
+                 up_temporal_idx=(0, 1))
+
+
+def build_vsr(sd, **kw):
+    from lavie_amd.vsr import UNet3DVSRModel
+    net = UNet3DVSRModel(init_weights=False, **kw)
+    net.load_state_dict({k: v.to(torch.float16) for k, v in sd.items()})
+    return net.to("cuda", torch.float16)
+
+
+@pytest.fixture(scope="module")
+def small_vsr():
+    from lavie_amd import spec
+    from lavie_amd.config import UNetConfig
+    cfg = UNetConfig(in_channels=7, block_out_channels=(256, 512), cross_attention_dim=128, attn_levels=(False, True),
+                     layers_per_block=1, vsr_blocks=True, only_cross_attention=(True, False), vsr_temporal_modules=True,
+                     num_class_embeds=1000)
+    sd = G.synth16(spec.param_shapes(cfg), 31)
+    return build_vsr(sd, **SMALL_VSR), sd
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 8, 8, 77), (1, 8, 8, 16, 77), (3, 2, 4, 4, 10)])
+def test_vsr_whole_unet_small_vs_oracle(small_vsr, shape):
+    """temporal modules after every block, class-embedded noise level, 4 + 3 input channels; ragged clip lengths."""
+    from oracle import vsr_blocks as V
+    net, sd = small_vsr
+    b, f, h, w, n = shape
+    g = torch.Generator().manual_seed(b * 100 + f)
+    x, low = torch.randn(b, 4, f, h, w, generator=g).half(), torch.randn(b, 3, f, h, w, generator=g).half()
+    ctx = torch.randn(b, n, 128, generator=g).half()
+    t = torch.tensor([41.0 * (i + 1) for i in range(b)])
+    labels = torch.tensor([20, 250, 7][:b])
+    ref = V.vsr_unet_forward(sd, x.float(), low.float(), t, ctx.float(), labels, block_out_channels=(256, 512),
+                             attn_levels=(False, True), only_cross_attention=(True, False), layers_per_block=1, heads=8)
+    got = net(x.cuda(), t.cuda(), low.cuda(), encoder_hidden_states=ctx.cuda(), class_labels=labels).sample
+    assert rel_l2(got, ref) < TOL_UNET
+
+
+def test_vsr_whole_unet_full_width_golden():
+    """UNet3DVSRModel at vsr/configs/unet_3d_config.json's width (691 M parameters) against the reference's own output."""
+    from lavie_amd import spec
+    from lavie_amd.config import VSR_CONFIG
+    fx = G.load("vsr_unet_full_8x8.pt")
+    sd = G.synth16(spec.param_shapes(VSR_CONFIG), fx["seed"])
+    net = build_vsr(sd, sample_size=128, down_temporal_idx=(0, 1, 2, 3), mid_temporal=True, up_temporal_idx=(0, 1, 2, 3))
+    for t, ref in fx["y"].items():
+        got = net(fx["x"].cuda(), int(t), fx["low_res"].cuda(), encoder_hidden_states=fx["ctx"].cuda(),
+                  class_labels=fx["labels"]).sample
+        assert rel_l2(got, ref) < TOL_UNET, t
+    with pytest.raises(ValueError):
+        net(fx["x"].cuda(), 5, fx["low_res"].cuda(), encoder_hidden_states=fx["ctx"].cuda(), class_labels=torch.tensor([400, 1]))

@@ -143,3 +143,21 @@ def test_vsr_resnet_block_3dcnn():
         sd = G.synth16(c["shapes"], c["seed"], "r.")
         got = V.resnet_block_3dcnn(sd, "r.", c["x"].float(), c["temb"].float())
         assert rel_l2(got, c["y"]) < 1e-5, (c["c"], c["taps"])
+
+
+def test_vsr_whole_unet_full_width():
+    from lavie_amd.config import VSR_CONFIG
+    from oracle import vsr_blocks as V
+    fx = G.load("vsr_unet_full_8x8.pt")
+    sd = G.synth16(spec.param_shapes(VSR_CONFIG), fx["seed"])
+    for t, ref in fx["y"].items():
+        got = V.vsr_unet_forward(sd, fx["x"].float(), fx["low_res"].float(), int(t), fx["ctx"].float(), fx["labels"])
+        assert rel_l2(got, ref) < 1e-4, t
+
+
+def test_vsr_transformer3d():
+    from oracle import vsr_blocks as V
+    for c in G.load("vsr_transformer3d.pt")["cases"]:
+        sd = G.synth16(c["shapes"], c["seed"], "t.")
+        got = V.vsr_transformer3d(sd, "t.", c["x"].float(), c["ctx"].float(), 8, c["only_cross"])
+        assert rel_l2(got, c["y"]) < 1e-5, c["c"]
