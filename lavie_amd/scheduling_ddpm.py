@@ -43,6 +43,13 @@ class DDPMScheduler:
             betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
         elif beta_schedule == "scaled_linear":
             betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "squaredcos_cap_v2":
+            # the cosine schedule of the x4-upscaler's low-res scheduler; in-tree statement of the same function:
+            # interpolation/diffusion/gaussian_diffusion.py:116-140 (betas_for_alpha_bar, max_beta 0.999)
+            import math
+            bar = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+            betas = torch.tensor([min(1 - bar((i + 1) / num_train_timesteps) / bar(i / num_train_timesteps), 0.999)
+                                  for i in range(num_train_timesteps)], dtype=torch.float32)
         else:
             raise NotImplementedError(f"{beta_schedule} is not implemented for DDPMScheduler")
         self.betas = betas
@@ -65,6 +72,14 @@ class DDPMScheduler:
 
     def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
         return sample
+
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """q(x_t | x_0) = sqrt(abar_t) x_0 + sqrt(1 - abar_t) noise, per batch entry — the low-res conditioning of the VSR
+        pipeline (pipeline_stable_diffusion_upscale_video_3d.py:631-633)."""
+        ab = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        t = torch.as_tensor(timesteps, device=original_samples.device).reshape(-1)
+        shape = (-1,) + (1,) * (original_samples.dim() - 1)
+        return ab[t].sqrt().reshape(shape) * original_samples + (1 - ab[t]).sqrt().reshape(shape) * noise
 
     def coefficients(self, timestep: int) -> Tuple[float, float, float, float, float]:
         """(k_x, k_eps, c_x0, c_xt, sigma): x0 = k_x x - k_eps eps;  x_prev = c_x0 x0 + c_xt x + sigma z."""

@@ -141,3 +141,38 @@ def test_vsr_whole_unet_full_width_golden():
         assert rel_l2(got, ref) < TOL_UNET, t
     with pytest.raises(ValueError):
         net(fx["x"].cuda(), 5, fx["low_res"].cuda(), encoder_hidden_states=fx["ctx"].cuda(), class_labels=torch.tensor([400, 1]))
+
+
+def test_vsr_pipeline_loop_vs_oracle(small_vsr):
+    """VideoUpscalePipeline.__call__ (noise-level conditioning of the low-res frames, DDIM loop through the fused
+    guidance + step kernel, class labels = noise level) against oracle/vsr_loop.py with the same host noise; and the 8-frame
+    chunk driver of vsr/sample.py:104-123."""
+    from lavie_amd.scheduling_ddim import DDIMScheduler
+    from lavie_amd.vsr import VideoUpscalePipeline, upscale_in_chunks
+    from oracle import vsr_blocks as V
+    from oracle.ddim import DDIMSchedule
+    from oracle.vsr_loop import add_low_res_noise, vsr_denoise_loop
+    net, sd = small_vsr
+    pipe = VideoUpscalePipeline(unet=net, scheduler=DDIMScheduler())
+    g = torch.Generator().manual_seed(77)
+    pe, ne = torch.randn(1, 77, 128, generator=g).half().float(), torch.randn(1, 77, 128, generator=g).half().float()
+    frames = torch.randn(1, 3, 4, 8, 8, generator=g).clamp(-1, 1)
+    lat = torch.randn(1, 4, 4, 8, 8, generator=g)
+    seen = []
+    out = pipe(image=frames, prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, num_inference_steps=3, guidance_scale=9.0,
+               noise_level=20, generator=torch.Generator().manual_seed(5), callback=lambda i, t, x: seen.append(t)).images
+    assert seen == [667, 334, 1] and out.shape == (1, 4, 4, 8, 8) and torch.isfinite(out).all()
+    noise = torch.randn(frames.shape, generator=torch.Generator().manual_seed(5))
+    img = add_low_res_noise(frames, noise, 20)
+    unet = lambda x, low, t, ctx, labels: V.vsr_unet_forward(sd, x, low, t, ctx, labels, block_out_channels=(256, 512),
+                                                            attn_levels=(False, True), only_cross_attention=(True, False),
+                                                            layers_per_block=1, heads=8)
+    ref = vsr_denoise_loop(unet, lat, img, pe, ne, 20, 3, 9.0, schedule=DDIMSchedule())
+    assert rel_l2(out, ref) < 3e-2
+    # chunk driver: 10 frames -> chunks of 8 + 2, concatenated along the frame axis
+    long = torch.randn(1, 3, 10, 8, 8, generator=g).clamp(-1, 1)
+    up = upscale_in_chunks(pipe, long, short_seq=8, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=2,
+                           guidance_scale=9.0, noise_level=20, generator=torch.Generator().manual_seed(1))
+    assert up.shape == (1, 4, 10, 8, 8) and torch.isfinite(up).all()
+    with pytest.raises(ValueError, match="noise_level"):
+        pipe(image=frames, prompt_embeds=pe, negative_prompt_embeds=ne, noise_level=400)

@@ -228,3 +228,18 @@ def test_euler_scheduler_matches_oracle_and_fused_form():
         eps = toy(xin, float(t), ctx)
         x = s.step(eps[0:1] + 3.0 * (eps[1:2] - eps[0:1]), t, x).prev_sample
     assert torch.allclose(x, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_vsr_low_res_noise_schedule_and_add_noise():
+    """DDPMScheduler(beta_schedule='squaredcos_cap_v2').add_noise (the VSR pipeline's low-res conditioning) against the
+    independently written oracle table."""
+    import numpy as np
+    from lavie_amd.scheduling_ddpm import DDPMScheduler
+    from oracle.vsr_loop import add_low_res_noise, cosine_alphas_cumprod
+    sch = DDPMScheduler(beta_schedule="squaredcos_cap_v2")
+    assert np.allclose(sch.alphas_cumprod.double().numpy(), cosine_alphas_cumprod(), rtol=2e-5)
+    g = torch.Generator().manual_seed(0)
+    img, noise = torch.randn(2, 3, 4, 5, 6, generator=g), torch.randn(2, 3, 4, 5, 6, generator=g)
+    for level in (0, 20, 350):
+        got = sch.add_noise(img, noise, torch.tensor([level, level]))
+        assert torch.allclose(got, add_low_res_noise(img, noise, level), rtol=1e-4, atol=1e-5)
