@@ -351,10 +351,13 @@ void igemm_force_splits(int s) { g_force_splits = s; }
 // (one workgroup per CU) and the K loop is long enough to amortise its 60 KiB prologue; an under-filled grid or a
 // short K loop loses.  Rule: N % 320 == 0, >= 10 K-tiles, the grid's last round at least 85 % full, and with
 // split-K at least 45 K-tiles per split (the fp32 slab round trip must stay small beside the loop).
+// tile width of the ping-pong kernel for this N: 320, or 256 (NT = 4) for the power-of-two widths of the VSR UNet; 0 = none
+static int pp_bn(int N) { return N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : 0); }
 static bool pp_fits(int M, int N, int nk, int s) {
-    if (N % 320 != 0 || nk < 10 || s < 1 || s > nk) return false;      // (5 K-tiles at N = 320 measured +0.2 %: within noise, not taken)
+    const int bn = pp_bn(N);
+    if (bn == 0 || nk < 10 || s < 1 || s > nk) return false;      // (5 K-tiles at N = 320 measured +0.2 %: within noise, not taken)
     if (s > 1 && nk / s < 45) return false;
-    const double r = (double)cdiv(M, 160) * (N / 320) * s / 256.0;
+    const double r = (double)cdiv(M, 160) * (N / bn) * s / 256.0;
     return r / ceil(r) >= 0.85;
 }
 // split-K factor with which the ping-pong kernel should run this problem, 0 = do not use it
@@ -466,7 +469,7 @@ int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len
 // Columns per row-statistics slot (= the wave tile width 16*NT) launch_igemm uses for a plain, unsplit EPI_LINEAR
 // GEMM; two waves share a tile's columns.
 int igemm_rowstat_cols(int M, int N, int nk) {
-    if ((g_force_tile & 0xF) == 3 ? N % 320 == 0 : (pp_plan(M, N, nk, EPI_LINEAR) == 1)) return 80;   // ping-pong wave tile
+    if ((g_force_tile & 0xF) == 3 ? N % 320 == 0 : (pp_plan(M, N, nk, EPI_LINEAR) == 1)) return pp_bn(N) / 4;   // ping-pong wave tile
     return igemm_pick_bn(M, N, 1) / 2;
 }
 
@@ -505,7 +508,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         return reduce_splits();
     }
     // 160x320 ping-pong kernel: forced (mode 3) or whenever the planner's rule holds for this problem at its split factor
-    if (p.N % 320 == 0 && !(gather && p.tframes > 0) && (lo == 3 || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits)))) {
+    if (!(gather && p.tframes > 0) && ((lo == 3 && p.N % 320 == 0) || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits)))) {
         if (int rc = launch_igemm_pp(p, gather, stream)) return rc;
         return reduce_splits();
     }

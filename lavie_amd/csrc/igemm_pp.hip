@@ -368,9 +368,13 @@ int launch_igemm_pp_geglu(const IgemmParams& p, hipStream_t stream) {
     return launch_pp_t<false, 0, EPI_GEGLU, 4>(p, stream);
 }
 
-// Launches the 160x320 ping-pong kernel (EPI_LINEAR only; the caller runs the split-K reduce).  N % 320 == 0.
+// Launches the 160x320 ping-pong kernel (EPI_LINEAR only; the caller runs the split-K reduce).  N % 320 == 0, or — the
+// widths of the VSR UNet (256 / 512 / 1024) — N % 256 == 0 with the 160x256 tile (NT = 4).
 int launch_igemm_pp(const IgemmParams& p, bool gather, hipStream_t stream) {
-    LAVIE_CHECK(p.N % 320 == 0, "igemm_pp: N=%d is not a multiple of 320", p.N);
+    if (p.N % 320 != 0) {
+        LAVIE_CHECK(p.N % 256 == 0, "igemm_pp: N=%d is not a multiple of 320 or 256", p.N);
+        return gather ? launch_pp_t<true, 0, EPI_LINEAR, 4>(p, stream) : launch_pp_t<false, 0, EPI_LINEAR, 4>(p, stream);
+    }
     if (gather && g_pp_abl == 1) return launch_pp_t<true, 1>(p, stream);
     if (gather && g_pp_abl == 2) return launch_pp_t<true, 2>(p, stream);
     if (gather && g_pp_abl == 3) return launch_pp_t<true, 3>(p, stream);

@@ -176,3 +176,40 @@ def test_vsr_pipeline_loop_vs_oracle(small_vsr):
     assert up.shape == (1, 4, 10, 8, 8) and torch.isfinite(up).all()
     with pytest.raises(ValueError, match="noise_level"):
         pipe(image=frames, prompt_embeds=pe, negative_prompt_embeds=ne, noise_level=400)
+
+
+def test_pingpong_256_wide_tile_bit_identical():
+    """The VSR widths (256 / 512 / 1024) are not multiples of 320: the ping-pong GEMM runs them with its 160x256 tile.
+    Kernel choice must not change numerics: automatic selection == the 128-row kernel, bit for bit (plain GEMM with bias +
+    residual, and a gathered 3x3 conv), and both match torch within the operator tolerance."""
+    import torch.nn.functional as F
+    from lavie_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 20480, 512, 1024
+    a = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = (torch.randn(M, N, generator=g) * 0.5).half().cuda()
+    outs = []
+    for mode in (0, 4):
+        lib.lavie_debug_force_tile(mode)
+        outs.append(ops.linear(a, w, bias=bias, residual=res))
+    lib.lavie_debug_force_tile(0)
+    assert torch.equal(outs[0], outs[1])
+    ref = a.float() @ w.float().t() + bias + res.float()
+    assert rel_l2(outs[0], ref) < TOL_OP
+    ni, h, wd, c = 16, 32, 40, 256
+    x = (torch.randn(ni, c, h, wd, generator=g) * 0.5).half()
+    wt = (torch.randn(c, c, 3, 3, generator=g) / (9 * c) ** 0.5).half()
+    xr = x.permute(0, 2, 3, 1).reshape(-1, c).contiguous().cuda()
+    wp = ops.pack_conv3x3(wt.cuda())
+    cb = torch.randn(c, generator=g).cuda()
+    outs = []
+    for mode in (0, 4):
+        lib.lavie_debug_force_tile(mode)
+        outs.append(ops.conv3x3(xr, wp, cb, ni, h, wd))
+    lib.lavie_debug_force_tile(0)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv2d(x.float(), wt.float(), cb.cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, c)
+    assert rel_l2(outs[0], ref) < TOL_OP
