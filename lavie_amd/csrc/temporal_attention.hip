@@ -256,7 +256,10 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
 }
 
 // LDS budget per workgroup for the three staged arrays: smaller tiles = more workgroups per CU in flight
-static int g_temporal_budget = 33000;   // measured best of 17/33/65 KB: ~4 workgroups per CU (profiles/r01_notes)
+// 0 = automatic: 33 KB for clips of <= 16 frames (measured best of 17/33/65 KB: ~4 workgroups per CU), 70 KB for the
+// 64-frame tile (61-frame interpolation clips: 4 heads per row segment instead of 2; measured 33 KB 1.39, 70 KB 1.72,
+// 135 KB 1.22 TB/s)
+static int g_temporal_budget = 0;
 void temporal_set_budget(int bytes) { g_temporal_budget = bytes; }
 
 int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
@@ -277,7 +280,8 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
         if (((rs / 32) & 1) == 0) rs += 32;
         return rs;
     };
-    const int budget = g_temporal_budget > 3 * FP * 256 ? g_temporal_budget : 3 * FP * 256;
+    const int want = g_temporal_budget > 0 ? g_temporal_budget : (NT == 1 ? 33000 : 70000);
+    const int budget = want > 3 * FP * 256 ? want : 3 * FP * 256;
     gm.HG = p.heads;
     while (gm.HG > 2 && gm.HG % 2 == 0 && 3 * FP * row_stride(gm.HG) > budget) gm.HG /= 2;
     LAVIE_CHECK((gm.HG * p.dh * 2) % 32 == 0, "temporal attention: head-group row (%d heads x %d) must be a multiple of 32 B", gm.HG, p.dh);

@@ -29,6 +29,8 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     lib = _lib.load()
+    if os.environ.get("LAVIE_TEMPORAL_BUDGET"):          # tuning: LDS bytes one temporal-attention workgroup may stage
+        lib.lavie_debug_temporal_budget(int(os.environ["LAVIE_TEMPORAL_BUDGET"]))
     sd = weights.synth_state_dict(spec.param_shapes(INTERPOLATION_CONFIG), 0)
     net = UNet3DConditionModel(init_weights=False, sample_size=64, in_channels=8, cross_attention_dim=768, use_first_frame=True)
     net.load_state_dict({k: v.half() for k, v in sd.items()})
