@@ -365,3 +365,38 @@ def test_pipeline_euler_scheduler(small):
     fn = lambda x, t, c: O.unet_forward(sd, x, t, c, ocfg_small())
     ref = cfg_euler_loop(fn, lat, pe.half().float(), ne.half().float(), num_steps=4, guidance_scale=7.5)
     assert rel_l2(out, ref) < 3e-2
+
+
+def test_pipeline_prompt_path_with_stock_text_encoder(small):
+    """SURVEY §8 f4 (first half): a stock transformers CLIPTextModel on the device + a tokenizer object attached to the
+    pipeline; `prompt=` / `negative_prompt=` go through `_encode_prompt` (pipeline_videogen.py:273-420: negative half first)
+    and give the same latents as passing the encoder's outputs as prompt_embeds."""
+    pytest.importorskip("transformers")
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    net, _ = small
+    torch.manual_seed(0)
+    enc = CLIPTextModel(CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                       num_attention_heads=4, max_position_embeddings=77, bos_token_id=0, eos_token_id=2)).cuda().eval()
+
+    class Tok:                       # stand-in for CLIPTokenizer (its vocabulary files are not in the image)
+        model_max_length = 77
+
+        def __call__(self, text, padding=None, max_length=77, truncation=True, return_tensors="pt"):
+            text = [text] if isinstance(text, str) else text
+            ids = torch.full((len(text), max_length), 2, dtype=torch.long)
+            for i, s in enumerate(text):
+                toks = [1 + (sum(map(ord, w)) % 900) for w in s.split()][: max_length - 1]
+                ids[i, : len(toks)] = torch.tensor(toks, dtype=torch.long)
+            from types import SimpleNamespace
+            return SimpleNamespace(input_ids=ids)
+
+    pipe = VideoGenPipeline(unet=net, text_encoder=enc, tokenizer=Tok())
+    lat = torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(1))
+    kw = dict(latents=lat, height=64, width=64, video_length=4, num_inference_steps=2, guidance_scale=7.5, output_type="latent")
+    a = pipe(prompt="a corgi walking in the park", negative_prompt="blurry", generator=torch.Generator().manual_seed(3), **kw).video
+    with torch.no_grad():
+        pe = enc(Tok()("a corgi walking in the park").input_ids.cuda())[0]
+        ne = enc(Tok()("blurry").input_ids.cuda())[0]
+    b = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, generator=torch.Generator().manual_seed(3), **kw).video
+    assert torch.isfinite(a).all() and torch.equal(a, b)
