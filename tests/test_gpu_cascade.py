@@ -85,3 +85,32 @@ def test_cascade_reduced_models():
     # are not guaranteed to be, so two runs agree to rounding, not to the bit
     assert torch.equal(outs[1][0], b)
     assert ((outs[1][2] - u).norm() / u.norm()).item() < 2e-2
+
+
+@pytest.mark.parametrize("widths,size", [((128, 256, 512, 512), (2, 8, 16)), ((128, 256, 512), (1, 16, 24))])
+def test_hip_vae_decoder_matches_stock_module(widths, size):
+    """AutoencoderKL.decode on the engine's conv / GroupNorm / GEMM operators (lavie_amd/vae_hip.py) against the stock
+    PyTorch module with the same weights in fp32 (both SD VAE layouts: factor 8 and the x4-upscaler's factor 4)."""
+    from lavie_amd.autoencoder_kl import AutoencoderKL
+    from lavie_amd.vae_hip import HipAutoencoderKL
+    torch.manual_seed(3)
+    vae = AutoencoderKL(block_out_channels=widths).cuda().eval()
+    n, h, w = size
+    z = torch.randn(n, 4, h, w, device="cuda")
+    ref = vae.decode(z).sample
+    got = HipAutoencoderKL(vae).decode(z).sample
+    assert got.shape == ref.shape == (n, 3, h * 2 ** (len(widths) - 1), w * 2 ** (len(widths) - 1))
+    assert ((got.float() - ref).norm() / ref.norm()).item() < 1e-2
+
+
+def test_hip_vae_encoder_matches_stock_module():
+    from lavie_amd.autoencoder_kl import AutoencoderKL
+    from lavie_amd.vae_hip import HipAutoencoderKL
+    torch.manual_seed(5)
+    vae = AutoencoderKL().cuda().eval()
+    x = torch.rand(2, 3, 64, 96, device="cuda") * 2 - 1
+    ref = vae.encode(x).latent_dist
+    got = HipAutoencoderKL(vae).encode(x).latent_dist
+    assert got.mean.shape == ref.mean.shape == (2, 4, 8, 12)
+    assert ((got.mean - ref.mean).norm() / ref.mean.norm()).item() < 1e-2
+    assert ((got.logvar - ref.logvar).norm() / ref.logvar.norm()).item() < 1e-2

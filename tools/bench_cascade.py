@@ -52,6 +52,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vsr-steps", type=int, default=50)
     ap.add_argument("--no-final-decode", action="store_true")
+    ap.add_argument("--stock-vae", action="store_true", help="decode with the stock PyTorch modules instead of lavie_amd.vae_hip")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -63,6 +64,9 @@ def main():
                               up_temporal_idx=(0, 1, 2, 3)), VSR_CONFIG, 2, dev)
     vae = AutoencoderKL().to(dev, torch.float16).eval()
     vsr_vae = AutoencoderKL(block_out_channels=(128, 256, 512), sample_size=256, scaling_factor=0.08333).to(dev).eval()   # fp32 (:737)
+    if not a.stock_vae:          # decoders on the engine's conv / GroupNorm / GEMM operators (encode stays stock)
+        from lavie_amd.vae_hip import HipAutoencoderKL
+        vae, vsr_vae = HipAutoencoderKL(vae), HipAutoencoderKL(vsr_vae)
     g = torch.Generator().manual_seed(0)
     e768 = lambda: torch.randn(1, 77, 768, generator=g).to(dev)
     e1024 = lambda: torch.randn(1, 77, 1024, generator=g).to(dev)
@@ -102,6 +106,7 @@ def main():
     print(json.dumps({"metric": "full cascade, one prompt, one GPU (BASELINE.json configs[4] per-rank work)", "seconds_total": total,
                       "stages": {k: round(v, 3) for k, v in t.items()}, "vsr_steps": a.vsr_steps, "output_frames_shape": shape,
                       "dtype": "f16 (UNets, base VAE) / f32 (final VSR VAE decode, as the reference)", "data": "synthetic",
+                      "vae_decode": "stock PyTorch" if a.stock_vae else "lavie_amd.vae_hip (engine operators)",
                       "hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
 
