@@ -46,7 +46,7 @@ struct IgemmParams {
     // Gather geometry (GATHER = true): output pixel grid [NI, Ho, Wo], source grid [NI, Hi, Wi],
     // virtual input grid (Hi << ups, Wi << ups) for the folded nearest-x2 upsample.
     int Ho, Wo, Hi, Wi, stride, ups;
-    // Temporal mode (tframes > 0; GATHER = true, 128-row kernel only): rows are tokens (b, f, pixel) with tpix pixels per
+    // Temporal mode (tframes > 0; GATHER = true; 128-row and ping-pong kernels): rows are tokens (b, f, pixel) with tpix pixels per
     // frame, and tap t of a segment with ntaps = T reads row m + (t - T/2) * tpix, or zeros when frame f + t - T/2 falls
     // outside [0, tframes) — nn.Conv3d with kernel (T, 1, 1), padding (T/2, 0, 0) (vsr/models/resnet.py:258-259, 274).
     int tframes, tpix;

@@ -508,7 +508,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         return reduce_splits();
     }
     // 160x320 ping-pong kernel: forced (mode 3) or whenever the planner's rule holds for this problem at its split factor
-    if (!(gather && p.tframes > 0) && ((lo == 3 && p.N % 320 == 0) || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits)))) {
+    if ((lo == 3 && p.N % 320 == 0) || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits))) {
         if (int rc = launch_igemm_pp(p, gather, stream)) return rc;
         return reduce_splits();
     }

@@ -90,6 +90,16 @@ __global__ __launch_bounds__(pp::THREADS, 2) void igemm_pp_kernel(const IgemmPar
     if constexpr (GATHER) {
         const int hw = p.Ho * p.Wo;
         const int Hv = p.Hi << p.ups, Wv = p.Wi << p.ups;
+        if (p.tframes > 0) {          // temporal taps (IgemmParams::tframes): slot t = the same pixel, t - T/2 frames away
+            const int T_ = p.seg[0].ntaps;
+            for (int idx = tid; idx < BM * 9; idx += THREADS) {
+                const int row = idx / 9, tap = idx - row * 9;
+                int m = m0 + row;
+                m = m < p.M ? m : p.M - 1;
+                const int ff = (m / p.tpix) % p.tframes + tap - (T_ >> 1);
+                tab[idx] = (tap < T_ && (unsigned)ff < (unsigned)p.tframes) ? m + (tap - (T_ >> 1)) * p.tpix : -1;
+            }
+        } else
         for (int idx = tid; idx < BM * 9; idx += THREADS) {
             const int row = idx / 9, tap = idx - row * 9;
             int m = m0 + row;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(pp::THREADS, 2) void igemm_pp_kernel(const IgemmPar
     int pv[5];
     auto prepare_read = [&]() {
         if constexpr (GATHER) {
-            const int tp = sg.ntaps == 9 ? tap : 4;
+            const int tp = sg.ntaps == 1 ? 4 : tap;
 #pragma unroll
             for (int j = 0; j < 5; ++j) pv[j] = tab[arow[j] * 9 + tp];
         }
