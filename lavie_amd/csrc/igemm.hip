@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
 // Split-K factor for an under-filled grid.  The 128-row tiles run 2 workgroups per CU (512 slots); a grid of
 // `blocks` tiles takes ceil(blocks*S/512) rounds of (nk/S + fixed) K-steps plus a reduce pass over S slabs.
 static int g_force_tile = 0;   // see igemm_force_tile() in igemm.h
-static int g_geglu_pp_min_nk = 16;   // measured: the GEGLU epilogue (no second workgroup to hide it) loses below ~16 K-tiles
+// measured: at 5 K-tiles (K = 320) the GEGLU epilogue, with no second workgroup to hide it, loses; from 8 K-tiles on the
+// ping-pong variant wins or ties (K = 640 of the base model: +0.2 %, K = 512 of the VSR UNet: GEMM class -3.5 %)
+static int g_geglu_pp_min_nk = 8;
 static int g_force_splits = 0;
 void igemm_force_splits(int s) { g_force_splits = s; }
 
