@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAVIE_ABI_VERSION 3
+#define LAVIE_ABI_VERSION 4
 #define LAVIE_MAX_LEVELS 8
 
 const char* lavie_last_error(void);
@@ -127,6 +127,11 @@ int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, v
 int lavie_cfg_sampler_step(const void* eps2, float* x, const float* noise, void* model_in2, long long n, float guidance,
                            float k_x, float k_eps, float c_x0, float c_xt, float sigma, float next_input_scale, void* stream);
 int lavie_latents_to_scaled_model_input(const float* x, void* model_in2, long long n, float input_scale, void* stream);
+/* The loop body without classifier-free guidance (`guidance_scale <= 1`: do_classifier_free_guidance is False,
+ * pipeline_videogen.py:626, 666, 678): eps fp16 [n] is used as it is, model_in fp16 [n] is the single copy x' * scale. */
+int lavie_sampler_step(const void* eps, float* x, const float* noise, void* model_in, long long n, float k_x, float k_eps,
+                       float c_x0, float c_xt, float sigma, float next_input_scale, void* stream);
+int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long long n, float input_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hook: HIP-event timing per kernel class on the launch stream (bench.py's roofline leg).
@@ -162,6 +167,9 @@ int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, d
 typedef struct lavie_unet_s* lavie_unet_t;
 
 typedef struct lavie_unet_config {
+    /* sizeof(lavie_unet_config) as the CALLER compiled / declared it.  lavie_unet_create rejects any other value, so a
+     * binding written against an older (shorter) layout fails with a message instead of being read past its end. */
+    int struct_size;
     int in_channels, out_channels;
     int num_levels;
     int block_out_channels[LAVIE_MAX_LEVELS];
@@ -196,6 +204,8 @@ typedef struct lavie_unet_config {
     int num_class_embeds;
 } lavie_unet_config;
 
+/* sizeof(lavie_unet_config) in this build of the library: what cfg->struct_size must hold. */
+int lavie_unet_config_size(void);
 int lavie_unet_create(const lavie_unet_config* cfg, lavie_unet_t* out);
 int lavie_unet_destroy(lavie_unet_t h);
 /* Number of state-dict entries the model expects and the i-th name/numel (reference key names,

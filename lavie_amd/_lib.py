@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LEVELS = 8
 
 c_void_p, c_int, c_float, c_ll, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_char_p
@@ -16,6 +16,7 @@ c_float_p = C.c_void_p      # fp32 device pointers are passed as raw addresses
 
 class UNetConfigC(C.Structure):
     _fields_ = [
+        ("struct_size", c_int),
         ("in_channels", c_int), ("out_channels", c_int), ("num_levels", c_int),
         ("block_out_channels", c_int * MAX_LEVELS), ("attn_levels", c_int * MAX_LEVELS),
         ("layers_per_block", c_int), ("heads", c_int), ("cross_attention_dim", c_int), ("norm_groups", c_int),
@@ -57,6 +58,9 @@ SIGNATURES = {
     "lavie_cfg_sampler_step": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_ll, c_float, c_float, c_float, c_float,
                                         c_float, c_float, c_float, c_void_p]),
     "lavie_latents_to_scaled_model_input": (c_int, [c_float_p, c_void_p, c_ll, c_float, c_void_p]),
+    "lavie_sampler_step": (c_int, [c_void_p, c_float_p, c_float_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float,
+                                    c_float, c_void_p]),
+    "lavie_latents_to_scaled_model_input1": (c_int, [c_float_p, c_void_p, c_ll, c_float, c_void_p]),
     "lavie_debug_force_tile": (c_int, [c_int]),
     "lavie_debug_force_splits": (c_int, [c_int]),
     "lavie_debug_conv_tap_major": (c_int, [c_int]),
@@ -66,6 +70,7 @@ SIGNATURES = {
     "lavie_profile_begin": (c_int, [C.c_uint, c_int]),
     "lavie_profile_end": (c_int, [c_void_p, C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
+    "lavie_unet_config_size": (c_int, []),
     "lavie_unet_create": (c_int, [C.POINTER(UNetConfigC), C.POINTER(c_void_p)]),
     "lavie_unet_destroy": (c_int, [c_void_p]),
     "lavie_unet_num_params": (c_int, [c_void_p]),

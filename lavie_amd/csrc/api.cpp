@@ -202,6 +202,17 @@ int lavie_cfg_sampler_step(const void* eps2, float* x, const float* noise, void*
                                 S(stream));
 }
 
+int lavie_sampler_step(const void* eps, float* x, const float* noise, void* model_in, long long n, float k_x, float k_eps,
+                       float c_x0, float c_xt, float sigma, float next_input_scale, void* stream) {
+    LAVIE_CHECK(eps && x && model_in && n > 0, "sampler_step: bad arguments");
+    return launch_sampler_step(H(eps), x, noise, H(model_in), n, k_x, k_eps, c_x0, c_xt, sigma, next_input_scale, S(stream));
+}
+
+int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long long n, float input_scale, void* stream) {
+    LAVIE_CHECK(x && model_in && n > 0, "latents_to_scaled_model_input1: bad arguments");
+    return launch_f32_to_f16_scaled(x, H(model_in), n, input_scale, S(stream));
+}
+
 int lavie_latents_to_model_input(const float* x, void* model_in2, long long n, void* stream) {
     LAVIE_CHECK(x && model_in2 && n > 0, "latents_to_model_input: bad arguments");
     return launch_f32_to_f16_dup2(x, H(model_in2), n, 1.0f, S(stream));
@@ -229,8 +240,14 @@ int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, d
     return profile_end(S(stream), launches_host, ms_host, flops_host, bytes_host);
 }
 
+int lavie_unet_config_size(void) { return (int)sizeof(lavie_unet_config); }
+
 int lavie_unet_create(const lavie_unet_config* cfg, lavie_unet_t* out) {
     LAVIE_CHECK(cfg && out, "unet_create: null argument");
+    // read only the first int until the caller's layout is known to be this build's
+    LAVIE_CHECK(cfg->struct_size == (int)sizeof(lavie_unet_config),
+                "unet_create: cfg->struct_size=%d but this library's lavie_unet_config has %d bytes (ABI %d): the binding's struct "
+                "layout is out of date", cfg->struct_size, (int)sizeof(lavie_unet_config), LAVIE_ABI_VERSION);
     LAVIE_CHECK(cfg->num_levels >= 1 && cfg->num_levels <= LAVIE_MAX_LEVELS, "unet_create: num_levels=%d", cfg->num_levels);
     lavie_unet_s* h = new (std::nothrow) lavie_unet_s(*cfg);
     LAVIE_CHECK(h != nullptr, "unet_create: out of host memory");

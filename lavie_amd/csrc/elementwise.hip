@@ -261,13 +261,19 @@ int launch_add_class_emb_silu(float* emb, const half_t* table, const int* labels
 
 // ------------------------------------------------------------------ CFG + DDPM step
 // pipeline_videogen.py:679-683 with the scheduler arithmetic of oracle/ddpm.py (diffusers DDPMScheduler.step).
-__global__ void cfg_ddpm_step_kernel(const half_t* __restrict__ eps2, float* __restrict__ x,
-                                     const float* __restrict__ noise, half_t* __restrict__ model_in2, long n,
-                                     float guidance, float kx, float ke, float c0, float ct, float sigma, float in_scale) {
+// CFG = false: guidance_scale <= 1, the pipeline's `do_classifier_free_guidance == False` branch (:626, 666, 678) — one
+// model batch entry per latent, eps used as it is, a single fp16 copy of the next model input.
+template <bool CFG>
+__global__ void sampler_step_kernel(const half_t* __restrict__ eps2, float* __restrict__ x,
+                                    const float* __restrict__ noise, half_t* __restrict__ model_in2, long n,
+                                    float guidance, float kx, float ke, float c0, float ct, float sigma, float in_scale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float eu = (float)eps2[i], ec = (float)eps2[n + i];
-    const float eps = eu + guidance * (ec - eu);
+    float eps = (float)eps2[i];
+    if (CFG) {
+        const float ec = (float)eps2[n + i];
+        eps = eps + guidance * (ec - eps);
+    }
     const float xt = x[i];
     const float x0 = kx * xt - ke * eps;
     float xn = c0 * x0 + ct * xt;
@@ -276,28 +282,45 @@ __global__ void cfg_ddpm_step_kernel(const half_t* __restrict__ eps2, float* __r
     // scheduler.scale_model_input of the NEXT step (Euler: 1 / sqrt(sigma_next^2 + 1); DDPM / DDIM: 1)
     const half_t h = (half_t)(xn * in_scale);
     model_in2[i] = h;
-    model_in2[n + i] = h;
+    if (CFG) model_in2[n + i] = h;
 }
 
 int launch_cfg_ddpm_step(const half_t* eps2, float* x, const float* noise, half_t* model_in2, int64_t n, float guidance,
                          float kx, float ke, float c0, float ct, float sigma, float in_scale, hipStream_t stream) {
     LAVIE_CHECK(sigma == 0.f || noise != nullptr, "ddpm step: sigma != 0 needs a noise tensor");
-    hipLaunchKernelGGL(cfg_ddpm_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, eps2, x, noise,
+    hipLaunchKernelGGL(sampler_step_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, eps2, x, noise,
                        model_in2, (long)n, guidance, kx, ke, c0, ct, sigma, in_scale);
     LAVIE_HIP(hipGetLastError());
     return 0;
 }
 
-__global__ void f32_to_f16_dup2_kernel(const float* __restrict__ x, half_t* __restrict__ out2, long n, float in_scale) {
+int launch_sampler_step(const half_t* eps, float* x, const float* noise, half_t* model_in, int64_t n, float kx, float ke,
+                        float c0, float ct, float sigma, float in_scale, hipStream_t stream) {
+    LAVIE_CHECK(sigma == 0.f || noise != nullptr, "sampler step: sigma != 0 needs a noise tensor");
+    hipLaunchKernelGGL(sampler_step_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, eps, x, noise,
+                       model_in, (long)n, 1.0f, kx, ke, c0, ct, sigma, in_scale);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+template <bool DUP>
+__global__ void f32_to_f16_kernel(const float* __restrict__ x, half_t* __restrict__ out2, long n, float in_scale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const half_t h = (half_t)(x[i] * in_scale);
     out2[i] = h;
-    out2[n + i] = h;
+    if (DUP) out2[n + i] = h;
 }
 
 int launch_f32_to_f16_dup2(const float* x, half_t* out2, int64_t n, float in_scale, hipStream_t stream) {
-    hipLaunchKernelGGL(f32_to_f16_dup2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, out2, (long)n,
+    hipLaunchKernelGGL(f32_to_f16_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, out2, (long)n,
+                       in_scale);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_f32_to_f16_scaled(const float* x, half_t* out, int64_t n, float in_scale, hipStream_t stream) {
+    hipLaunchKernelGGL(f32_to_f16_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, out, (long)n,
                        in_scale);
     LAVIE_HIP(hipGetLastError());
     return 0;

@@ -494,13 +494,17 @@ int UNet::finalize(hipStream_t s) {
         RUN(pack_sampler("down_blocks." + std::to_string(l) + ".downsamplers.0.conv", c.block_out_channels[l], &downs_[l], s));
     for (int i = 0; i + 1 < L; ++i)
         RUN(pack_sampler("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", c.block_out_channels[L - 1 - i], &ups_[i], s));
-    relbias_.assign(transformers_.size(), nullptr);
     finalized_ = true;
     return 0;
 }
 
 int UNet::ensure_tables(int F, hipStream_t s) {
-    if (tables_F_ == F) return 0;
+    auto it = tables_.find(F);
+    if (it != tables_.end()) {          // built before: switching clip length costs nothing and allocates nothing
+        cur_tables_ = &it->second;
+        return 0;
+    }
+    FrameTables ft;
     const int rp = cfg_.rotary_dim / 2;
     std::vector<float> hc((size_t)F * rp), hs((size_t)F * rp);
     for (int f = 0; f < F; ++f)
@@ -512,28 +516,30 @@ int UNet::ensure_tables(int F, hipStream_t s) {
         }
     std::vector<int> hb((size_t)F * F);
     relpos_bucket_table(F, cfg_.rel_buckets, cfg_.rel_max_distance, hb.data());
-    WALLOC(rot_cos_, float, (size_t)F * rp);
-    WALLOC(rot_sin_, float, (size_t)F * rp);
-    WALLOC(buckets_dev_, int, (size_t)F * F);
-    // pageable host memory: these copies complete before returning (tables are rebuilt only when F changes)
-    LAVIE_HIP(hipMemcpy(rot_cos_, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice));
-    LAVIE_HIP(hipMemcpy(rot_sin_, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
-    LAVIE_HIP(hipMemcpy(buckets_dev_, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice));
+    int* buckets_dev = nullptr;
+    WALLOC(ft.rot_cos, float, (size_t)F * rp);
+    WALLOC(ft.rot_sin, float, (size_t)F * rp);
+    WALLOC(buckets_dev, int, (size_t)F * F);
+    // pageable host memory: these copies complete before returning (once per distinct F in the handle's lifetime)
+    LAVIE_HIP(hipMemcpy(ft.rot_cos, hc.data(), hc.size() * sizeof(float), hipMemcpyHostToDevice));
+    LAVIE_HIP(hipMemcpy(ft.rot_sin, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
+    LAVIE_HIP(hipMemcpy(buckets_dev, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice));
+    ft.relbias.assign(transformers_.size(), nullptr);
     if (cfg_.temporal_plain) {
         // plain softmax(scale q k^T) v over frames (interpolation/models/attention.py:268-289): one shared all-zero bias
         // table (s + 0.0f == s exactly) and rot_dim = 0 in the kernel parameters
         float* zero = nullptr;
         WALLOC(zero, float, (size_t)cfg_.heads * F * F);
         LAVIE_HIP(hipMemsetAsync(zero, 0, (size_t)cfg_.heads * F * F * sizeof(float), s));
-        for (size_t i = 0; i < transformers_.size(); ++i) relbias_[i] = zero;
+        for (size_t i = 0; i < transformers_.size(); ++i) ft.relbias[i] = zero;
     } else {
         for (size_t i = 0; i < transformers_.size(); ++i) {
-            WALLOC(relbias_[i], float, (size_t)cfg_.heads * F * F);
-            RUN(launch_fill_relpos_bias(transformers_[i].relemb, buckets_dev_, relbias_[i], cfg_.heads, F, s));
+            WALLOC(ft.relbias[i], float, (size_t)cfg_.heads * F * F);
+            RUN(launch_fill_relpos_bias(transformers_[i].relemb, buckets_dev, ft.relbias[i], cfg_.heads, F, s));
         }
     }
     LAVIE_HIP(hipStreamSynchronize(s));
-    tables_F_ = F;
+    cur_tables_ = &tables_.emplace(F, std::move(ft)).first->second;
     return 0;
 }
 
@@ -842,7 +848,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         if (!c.dry) {
             TemporalParams tp;
             tp.qkv = wide; tp.ld = 3 * C; tp.o = att; tp.ldo = C; tp.B = c.B; tp.F = c.F; tp.D = D; tp.heads = heads; tp.dh = dh;
-            tp.bias = relbias_[ti]; tp.rot_cos = rot_cos_; tp.rot_sin = rot_sin_; tp.rot_dim = cfg_.temporal_plain ? 0 : cfg_.rotary_dim; tp.scale = scale;
+            tp.bias = cur_tables_->relbias[ti]; tp.rot_cos = cur_tables_->rot_cos; tp.rot_sin = cur_tables_->rot_sin; tp.rot_dim = cfg_.temporal_plain ? 0 : cfg_.rotary_dim; tp.scale = scale;
             RUN(launch_temporal_attention(tp, c.s));
         }
         // its output feeds norm3 only in the base order; in the interpolation order proj_out follows (no LayerNorm)
@@ -1031,7 +1037,6 @@ int UNet::prepare(int B, int F, int H, int W, int ctx_len) {
     RUN(run(c, nullptr, nullptr, nullptr, nullptr));
     const size_t need = plan.peak() + (1 << 20);
     if (need > ws_.total_bytes()) RUN(ws_.init_fixed(need));
-    prep_B_ = B; prep_F_ = F; prep_ctx_ = ctx_len;
     return 0;
 }
 

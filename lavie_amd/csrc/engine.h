@@ -155,13 +155,15 @@ private:
     std::vector<TemporalModuleW> tmods_;            // VSR: down 0..L-1, mid, up 0..L-1
     half_t* class_emb_ = nullptr;                   // [num_class_embeds][time_embed_dim] fp16 (state-dict tensor)
     half_t* zero_page_ = nullptr;
-    // per-F tables
-    int tables_F_ = 0;
-    float* rot_cos_ = nullptr; float* rot_sin_ = nullptr;
-    int* buckets_dev_ = nullptr;
-    std::vector<float*> relbias_;                   // one [heads, F, F] per transformer
-    // prepared geometry
-    int prep_B_ = 0, prep_F_ = 0, prep_H_ = 0, prep_W_ = 0, prep_ctx_ = 0;
+    // per-F tables, built once per clip length and kept (the VSR chunk driver alternates F = 8 and F = 5)
+    struct FrameTables {
+        float* rot_cos = nullptr; float* rot_sin = nullptr;
+        std::vector<float*> relbias;                // one [heads, F, F] per transformer
+    };
+    std::unordered_map<int, FrameTables> tables_;
+    const FrameTables* cur_tables_ = nullptr;       // the entry of the running forward's F
+    // spatial size of the running call (set by prepare()/forward() before run())
+    int prep_H_ = 0, prep_W_ = 0;
 };
 
 }  // namespace lavie

@@ -64,6 +64,9 @@ int launch_cfg_ddpm_step(const half_t* eps2, float* x, const float* noise, half_
                          float kx, float ke, float c0, float ct, float sigma, float in_scale, hipStream_t stream);
 int launch_add_class_emb_silu(float* emb, const half_t* table, const int* labels_host, int B, int N, hipStream_t stream);
 int launch_f32_to_f16_dup2(const float* x, half_t* out2, int64_t n, float in_scale, hipStream_t stream);
+int launch_sampler_step(const half_t* eps, float* x, const float* noise, half_t* model_in, int64_t n, float kx, float ke,
+                        float c0, float ct, float sigma, float in_scale, hipStream_t stream);
+int launch_f32_to_f16_scaled(const float* x, half_t* out, int64_t n, float in_scale, hipStream_t stream);
 int launch_fill_relpos_bias(const half_t* emb, const int* buckets, float* out, int heads, int F, hipStream_t stream);
 
 // ---- pack.hip : one-off weight repacking at load time

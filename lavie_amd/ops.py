@@ -237,6 +237,24 @@ def latents_to_model_input(x, model_in2, input_scale: float = 1.0):
     _lib.check(_lib.load().lavie_latents_to_scaled_model_input(_p(x), _p(model_in2), x.numel(), float(input_scale), _stream()))
 
 
+def sampler_step(eps, x, noise, model_in, coeffs, next_input_scale: float = 1.0):
+    """Scheduler update without classifier-free guidance (guidance_scale <= 1): eps / model_in are fp16 of x's size."""
+    _chk16(eps, model_in)
+    _chk32(x, noise)
+    if eps.numel() != x.numel() or model_in.numel() != x.numel():
+        raise ValueError("sampler_step: eps / model_in must have as many elements as x")
+    k_x, k_e, c_x0, c_xt, sigma = coeffs
+    _lib.check(_lib.load().lavie_sampler_step(_p(eps), _p(x), _p(noise), _p(model_in), x.numel(), float(k_x), float(k_e),
+                                              float(c_x0), float(c_xt), float(sigma), float(next_input_scale), _stream()),
+               "lavie_sampler_step")
+
+
+def latents_to_model_input1(x, model_in, input_scale: float = 1.0):
+    _chk32(x)
+    _chk16(model_in)
+    _lib.check(_lib.load().lavie_latents_to_scaled_model_input1(_p(x), _p(model_in), x.numel(), float(input_scale), _stream()))
+
+
 # ------------------------------------------------------------------ engine seams (sub-module forwards)
 def unet_resnet_block(net, prefix: str, x1, x2, temb, b: int, f: int, h: int, w: int):
     """ResnetBlock3D.forward of `net`'s block `prefix` on channels-last rows (x2 = skip half or None).

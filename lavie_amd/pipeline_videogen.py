@@ -114,7 +114,8 @@ class VideoGenPipeline:
     @torch.no_grad()
     def denoise(self, latents: torch.Tensor, ctx: torch.Tensor, num_inference_steps: int, guidance_scale: float,
                 generator=None, callback: Optional[Callable] = None, callback_steps: int = 1, eta: float = 0.0) -> torch.Tensor:
-        """latents fp32 [P, C, F, h, w] on the device, ctx fp16 [2P, n, d] = [negative | prompt] -> denoised fp32."""
+        """latents fp32 [P, C, F, h, w] on the device, ctx fp16 [2P, n, d] = [negative | prompt] (guidance_scale > 1) or
+        [P, n, d] = prompt only (guidance_scale <= 1: no classifier-free guidance, :626) -> denoised fp32."""
         dev = latents.device
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps)
@@ -127,17 +128,28 @@ class VideoGenPipeline:
         # (pipeline_videogen.py:431-446); DDPM ignores it
         takes_eta = "eta" in inspect.signature(sch.coefficients).parameters
         do_cfg = guidance_scale > 1.0
-        if not do_cfg:
-            raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance) is outside the fused MI355X loop")
         x = latents.to(torch.float32).contiguous().clone()
         p = x.shape[0]
-        model_in = torch.empty((2 * p,) + tuple(x.shape[1:]), dtype=torch.float16, device=dev)
-        ops.latents_to_model_input(x, model_in, in_scale(timesteps[0]) if in_scale else 1.0)
-        self.unet.prepare(2 * p, x.shape[2], x.shape[3], x.shape[4], ctx.shape[1])
+        nb = 2 * p if do_cfg else p                        # model batch (:666)
+        if ctx.shape[0] != nb:
+            raise ValueError(f"ctx has {ctx.shape[0]} rows, expected {nb} for {p} latents at guidance_scale={guidance_scale}")
+        model_in = torch.empty((nb,) + tuple(x.shape[1:]), dtype=torch.float16, device=dev)
+        first_scale = in_scale(timesteps[0]) if in_scale else 1.0
+        if do_cfg:
+            ops.latents_to_model_input(x, model_in, first_scale)
+        else:
+            ops.latents_to_model_input1(x, model_in, first_scale)
+        self.unet.prepare(nb, x.shape[2], x.shape[3], x.shape[4], ctx.shape[1])
 
         # per-step noise: drawn on the host only when the caller's generator lives there, then staged through
         # two pinned slots on a side stream so that neither the device nor the host waits for the other
-        host_noise = generator is not None and not isinstance(generator, list) and generator.device.type == "cpu"
+        gens = generator if isinstance(generator, list) else ([generator] if generator is not None else [])
+        if isinstance(generator, list):                    # one generator per latent, as randn_tensor takes them (:504)
+            if len(gens) != p:
+                raise ValueError(f"got a list of {len(gens)} generators for {p} latents")
+            if len({g.device.type for g in gens}) != 1:
+                raise ValueError("a list of generators must live on one device type")
+        host_noise = bool(gens) and gens[0].device.type == "cpu"
         noise_dev = torch.empty_like(x)
         if host_noise:
             pinned = [torch.empty(x.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -158,7 +170,11 @@ class VideoGenPipeline:
                 if host_noise:
                     if copy_done[slot] is not None:
                         copy_done[slot].synchronize()
-                    torch.randn(x.shape, generator=generator, dtype=torch.float32, out=pinned[slot])
+                    if isinstance(generator, list):
+                        for j, g in enumerate(gens):
+                            torch.randn(x.shape[1:], generator=g, dtype=torch.float32, out=pinned[slot][j])
+                    else:
+                        torch.randn(x.shape, generator=generator, dtype=torch.float32, out=pinned[slot])
                     if step_done[slot] is not None:
                         self._copy_stream.wait_event(step_done[slot])
                     with torch.cuda.stream(self._copy_stream):
@@ -167,10 +183,17 @@ class VideoGenPipeline:
                     copy_done[slot].record(self._copy_stream)
                     main.wait_event(copy_done[slot])
                     noise = staged[slot]
+                elif isinstance(generator, list):
+                    for j, g in enumerate(gens):
+                        noise_dev[j].normal_(generator=g)
+                    noise = noise_dev
                 else:
                     noise = noise_dev.normal_(generator=generator) if generator is not None else noise_dev.normal_()
             next_scale = in_scale(timesteps[i + 1]) if in_scale and i + 1 < len(timesteps) else 1.0
-            ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs, next_scale)   # lines 667, 679-683 fused
+            if do_cfg:
+                ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs, next_scale)   # lines 667, 679-683 fused
+            else:
+                ops.sampler_step(eps, x, noise, model_in, coeffs, next_scale)                    # lines 667, 683
             if host_noise and coeffs[4] != 0.0:
                 step_done[slot] = torch.cuda.Event()
                 step_done[slot].record(main)

@@ -83,15 +83,22 @@ def gather_latents(local: torch.Tensor, counts: Sequence[int]) -> List[torch.Ten
 
 def run_prompts(denoise_one: Callable[[int], torch.Tensor], num_prompts: int) -> Tuple[List[int], List[torch.Tensor]]:
     """Runs this rank's prompts through `denoise_one(prompt_index) -> latents [1, ...]`, gathers everything and
-    returns (prompt indices, latents) in global prompt order on every rank."""
+    returns (prompt indices, latents) in global prompt order on every rank.  With fewer prompts than ranks the idle
+    ranks contribute a zero-row buffer (rank 0, which always owns prompt 0, tells them the latent shape), so every rank
+    reaches the collective: no rank ever raises while the others wait in all_gather."""
     rank, size = world()
+    if num_prompts < 1:                      # known to every rank: all of them raise, none enters a collective
+        raise ValueError("run_prompts needs at least one prompt")
     mine = shard_prompts(num_prompts, rank, size)
     outs = [denoise_one(i) for i in mine]
     counts = [len(shard_prompts(num_prompts, r, size)) for r in range(size)]
-    if outs:
-        local = torch.cat(outs, dim=0)
-    else:
-        raise ValueError("every rank needs at least one prompt (num_prompts >= world size)")
+    local = torch.cat(outs, dim=0) if outs else None
+    if size > 1 and min(counts) == 0:
+        meta = [(tuple(local.shape[1:]), local.dtype) if rank == 0 else None]
+        dist.broadcast_object_list(meta, src=0)
+        if local is None:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            local = torch.zeros((0,) + meta[0][0], dtype=meta[0][1], device=dev)
     parts = gather_latents(local, counts)
     order, tensors = [], []
     for r, part in enumerate(parts):

@@ -3,15 +3,19 @@
 
 The reference takes `DDIMScheduler` from diffusers 0.16.0 (not in its tree), but it also VENDORS that class's text
 in `vsr/diffusion/scheduling_ddim.py`; this file follows the vendored text: constructor :137-182, `_get_variance`
-:198-207, `set_timesteps` :243-265 (the stock "leading" spacing, kept there as a comment) and :267-285 (the
-linspace variant the VSR stage runs, `timestep_spacing="vsr_linspace"`), `step` :286-405.  Epsilon prediction, no
-sample clipping / thresholding (SD-1.4's scheduler_config.json: clip_sample=false, set_alpha_to_one=false,
-steps_offset=1).
+:198-207, `set_timesteps` :243-265 (the stock "leading" spacing, kept there as a comment), `step` :286-405 with its
+three prediction types (:354-363).  No sample clipping / thresholding (SD-1.4's scheduler_config.json: clip_sample=false,
+set_alpha_to_one=false, steps_offset=1).
+
+`timestep_spacing="vsr_linspace"` reproduces the vendored file's live `set_timesteps` (:267-285: linspace + offset).
+Nothing in the reference runs that text: vsr/sample.py:19,53 installs the STOCK `diffusers.DDIMScheduler.from_config(
+x4-upscaler scheduler_config.json)` with only beta_schedule overridden, and the vendored variant's first timestep
+(1001 at 50 steps, 1000 with steps_offset 0) lies past its own 1000-entry alpha table.  The mode is kept so the
+timestep list can be compared with the vendored class; `coefficients` / `step` raise for a timestep outside the table.
 
 `coefficients(t, eta)` exposes the five scalars of one step in the form of the fused HIP kernel
-(`lavie_cfg_ddpm_step`: x0 = k_x x - k_eps eps;  x_prev = c_x0 x0 + c_xt x + sigma z): with a = sqrt(abar_prev) and
-b = sqrt(1 - abar_prev - sigma^2), DDIM's  x_prev = a x0 + b eps + sigma z  equals that form for
-c_x0 = a - b / k_eps and c_xt = b k_x / k_eps  (eps = (k_x x - x0) / k_eps)."""
+(`lavie_cfg_ddpm_step`: x0 = k_x x - k_m m;  x_prev = c_x0 x0 + c_xt x + sigma z, m = the guided model output);
+derivation in its docstring."""
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Optional, Tuple, Union
@@ -35,8 +39,10 @@ class DDIMScheduler:
                  beta_schedule: str = "linear", clip_sample: bool = False, set_alpha_to_one: bool = False,
                  steps_offset: int = 1, prediction_type: str = "epsilon", thresholding: bool = False,
                  timestep_spacing: str = "leading"):
-        if clip_sample or thresholding or prediction_type != "epsilon":
-            raise NotImplementedError("only epsilon prediction without sample clipping / thresholding is supported")
+        if clip_sample or thresholding:
+            raise NotImplementedError("sample clipping / thresholding are not supported")
+        if prediction_type not in ("epsilon", "sample", "v_prediction"):
+            raise ValueError(f"prediction_type given as {prediction_type} must be one of `epsilon`, `sample`, or `v_prediction`")
         if timestep_spacing not in ("leading", "vsr_linspace"):
             raise NotImplementedError(f"timestep_spacing={timestep_spacing!r}")
         if beta_schedule == "linear":                                                   # scheduling_ddim.py:155-156
@@ -75,6 +81,9 @@ class DDIMScheduler:
         self.timesteps = steps.to(device) if device is not None else steps
 
     def _alphas(self, t: int) -> Tuple[float, float]:
+        if not 0 <= t < self.config.num_train_timesteps:
+            raise ValueError(f"timestep {t} is outside the {self.config.num_train_timesteps}-entry alpha table"
+                             " (timestep_spacing='vsr_linspace' starts past it: see the module docstring)")
         prev = t - self.config.num_train_timesteps // self.num_inference_steps             # :343
         a_t = float(self.alphas_cumprod[t])                                                # :346
         a_prev = float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)   # :347
@@ -84,15 +93,29 @@ class DDIMScheduler:
         return ((1.0 - a_prev) / (1.0 - a_t)) * (1.0 - a_t / a_prev)
 
     def coefficients(self, timestep: int, eta: float = 0.0) -> Tuple[float, float, float, float, float]:
-        """(k_x, k_eps, c_x0, c_xt, sigma) of the fused kernel form; see the module docstring."""
+        """(k_x, k_m, c_x0, c_xt, sigma) of the fused kernel form (m = the model output after guidance):
+        x0 = k_x x - k_m m;  x_prev = c_x0 x0 + c_xt x + sigma z.  With a = sqrt(abar_prev), b = sqrt(1 - abar_prev -
+        sigma^2) DDIM's update is x_prev = a x0 + b eps + sigma z (:389-392), and eps is linear in (x, x0) for every
+        prediction type (:354-363):
+          epsilon       x0 = (x - sqrt(1-abar) m) / sqrt(abar)      eps = (x - sqrt(abar) x0) / sqrt(1-abar)
+          v_prediction  x0 = sqrt(abar) x - sqrt(1-abar) m          eps = sqrt(abar) m + sqrt(1-abar) x   (same eps(x, x0))
+          sample        x0 = m                                      eps = (x - sqrt(abar) x0) / sqrt(1-abar)
+        so c_x0 = a - b sqrt(abar) / sqrt(1-abar) and c_xt = b / sqrt(1-abar) in all three."""
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         a_t, a_prev = self._alphas(int(timestep))
         sigma = eta * max(self._variance(a_t, a_prev), 0.0) ** 0.5                         # :381-382
-        k_x, k_e = 1.0 / a_t ** 0.5, ((1.0 - a_t) ** 0.5) / a_t ** 0.5                     # :354
+        sa, sb = a_t ** 0.5, (1.0 - a_t) ** 0.5
+        kind = self.config.prediction_type
+        if kind == "epsilon":
+            k_x, k_m = 1.0 / sa, sb / sa                                                   # :354
+        elif kind == "v_prediction":
+            k_x, k_m = sa, sb                                                              # :360
+        else:
+            k_x, k_m = 0.0, -1.0                                                           # :357  x0 = m
         a = a_prev ** 0.5
         b = max(1.0 - a_prev - sigma * sigma, 0.0) ** 0.5                                  # :389
-        return k_x, k_e, a - b / k_e, b * k_x / k_e, sigma
+        return k_x, k_m, a - b * sa / sb, b / sb, sigma
 
     def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, eta: float = 0.0,
              use_clipped_model_output: bool = False, generator=None, variance_noise: Optional[torch.Tensor] = None,
@@ -103,8 +126,15 @@ class DDIMScheduler:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         a_t, a_prev = self._alphas(int(timestep))
         beta_prod_t = 1.0 - a_t
-        pred_original_sample = (sample - beta_prod_t ** 0.5 * model_output) / a_t ** 0.5     # :354
-        pred_epsilon = model_output
+        if self.config.prediction_type == "epsilon":
+            pred_original_sample = (sample - beta_prod_t ** 0.5 * model_output) / a_t ** 0.5     # :354
+            pred_epsilon = model_output
+        elif self.config.prediction_type == "sample":                                         # :356-358
+            pred_original_sample = model_output
+            pred_epsilon = (sample - a_t ** 0.5 * pred_original_sample) / beta_prod_t ** 0.5
+        else:                                                                                 # v_prediction, :359-361
+            pred_original_sample = a_t ** 0.5 * sample - beta_prod_t ** 0.5 * model_output
+            pred_epsilon = a_t ** 0.5 * model_output + beta_prod_t ** 0.5 * sample
         std_dev_t = eta * self._variance(a_t, a_prev) ** 0.5                                  # :381-382
         pred_sample_direction = (1.0 - a_prev - std_dev_t ** 2) ** 0.5 * pred_epsilon         # :389
         prev_sample = a_prev ** 0.5 * pred_original_sample + pred_sample_direction            # :392

@@ -25,6 +25,10 @@ def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
     """Noise helper with diffusers' contract (pipeline_videogen.py:504): a CPU generator draws on the
     CPU and the result is moved, so trajectories are reproducible across devices."""
     device = torch.device(device) if device is not None else torch.device("cpu")
+    if isinstance(generator, (list, tuple)):               # one generator per batch entry, results concatenated
+        if len(generator) != shape[0]:
+            raise ValueError(f"got {len(generator)} generators for a batch of {shape[0]}")
+        return torch.cat([randn_tensor((1,) + tuple(shape[1:]), g, device, dtype) for g in generator], dim=0)
     gen_dev = generator.device.type if generator is not None else device.type
     if gen_dev == "cpu" and device.type != "cpu":
         return torch.randn(shape, generator=generator, dtype=dtype).to(device)

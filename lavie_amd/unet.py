@@ -186,6 +186,7 @@ class UNet3DConditionModel(nn.Module):
     # ------------------------------------------------------------------ engine
     def _config_c(self) -> "_lib.UNetConfigC":
         c = _lib.UNetConfigC()
+        c.struct_size = ctypes.sizeof(_lib.UNetConfigC)
         cfg = self.cfg
         c.in_channels, c.out_channels = cfg.in_channels, cfg.out_channels
         c.num_levels = len(cfg.block_out_channels)

@@ -15,8 +15,9 @@ import torch
 class DDIMSchedule:
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 1e-4, beta_end: float = 0.02,
                  beta_schedule: str = "linear", set_alpha_to_one: bool = False, steps_offset: int = 1,
-                 timestep_spacing: str = "leading"):
+                 timestep_spacing: str = "leading", prediction_type: str = "epsilon"):
         self.num_train_timesteps = num_train_timesteps
+        self.prediction_type = prediction_type
         if beta_schedule == "linear":                                   # scheduling_ddim.py:155-156
             self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
         else:                                                           # "scaled_linear", :157-161
@@ -42,7 +43,15 @@ class DDIMSchedule:
         prev = t - self.num_train_timesteps // self.num_inference_steps                       # :343
         a_t = self.alphas_cumprod[t].item()                                                   # :346
         a_prev = self.alphas_cumprod[prev].item() if prev >= 0 else self.final_alpha_cumprod  # :347
-        x0 = (x - (1.0 - a_t) ** 0.5 * eps) / a_t ** 0.5                                      # :354
+        if self.prediction_type == "epsilon":
+            x0 = (x - (1.0 - a_t) ** 0.5 * eps) / a_t ** 0.5                                  # :354
+        elif self.prediction_type == "sample":                                                # :356-358 (`eps` = model output)
+            x0 = eps
+            eps = (x - a_t ** 0.5 * x0) / (1.0 - a_t) ** 0.5
+        else:                                                                                 # "v_prediction", :359-361
+            v = eps
+            x0 = a_t ** 0.5 * x - (1.0 - a_t) ** 0.5 * v
+            eps = a_t ** 0.5 * v + (1.0 - a_t) ** 0.5 * x
         var = ((1.0 - a_prev) / (1.0 - a_t)) * (1.0 - a_t / a_prev)                           # :198-207
         std = eta * var ** 0.5                                                                # :382
         out = a_prev ** 0.5 * x0 + (1.0 - a_prev - std ** 2) ** 0.5 * eps                     # :389-392

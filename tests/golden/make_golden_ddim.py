@@ -40,9 +40,24 @@ def main():
     for t in ts:
         eps = torch.tanh(x * 0.7 + 0.01 * t / 1000.0)       # any deterministic function of (x, t)
         x = sch.step(eps, t, x, eta=0.0).prev_sample
+    # the other two prediction types of the vendored step (:356-363); v_prediction is what the x4-upscaler's own
+    # scheduler_config.json is published with (the file is not in the reference tree)
+    pcases = []
+    for kind in ("v_prediction", "sample"):
+        psch = DDIM(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, beta_schedule="linear", clip_sample=False,
+                    set_alpha_to_one=False, steps_offset=1, prediction_type=kind)
+        psch.set_timesteps(50)
+        for t in (981, 501, 1):
+            for eta in (0.0, 0.5):
+                xx = torch.randn(1, 4, 4, 8, 8, generator=g)
+                m = torch.randn(1, 4, 4, 8, 8, generator=g)
+                z = torch.randn(1, 4, 4, 8, 8, generator=g)
+                out = psch.step(m, t, xx, eta=eta, variance_noise=z if eta > 0 else None)
+                pcases.append(dict(kind=kind, t=t, eta=eta, x=xx, model_output=m, noise=z, prev=out.prev_sample,
+                                   x0=out.pred_original_sample))
     path = os.path.join(HERE, "ddim_steps.pt")
     torch.save(dict(vsr_timesteps_50=vsr_timesteps, alphas_cumprod=sch.alphas_cumprod.clone(), cases=cases,
-                    chain=dict(x=chain_in, timesteps=ts, y=x)), path)
+                    chain=dict(x=chain_in, timesteps=ts, y=x), prediction_cases=pcases), path)
     print(f"wrote ddim_steps.pt: {os.path.getsize(path) / 1024:.0f} KiB")
 
 

@@ -283,6 +283,52 @@ def test_three_ddpm_steps_golden(full):
     assert rel_l2(x, fx["y"]) < TOL_UNET
 
 
+def test_fifty_ddpm_steps_reference_trajectory(full):
+    """BASELINE's north star: "outputs match the reference CPU path on the same seed/prompt within a stated fp16
+    tolerance".  All 50 CFG + DDPM steps of VideoGenPipeline.__call__ (latents=, prompt_embeds=, CPU generator=) at full
+    width against tests/golden/ddpm_50step.pt — the reference loop (pipeline_videogen.py:662-689) around the imported
+    reference UNet in fp32, noise from the same CPU generator seed.  Stated tolerance for fp16 storage over the whole
+    stochastic trajectory: rel-L2 <= 3e-2 and cosine >= 0.999 on the final latents, rel-L2 <= 2e-2 on every kept
+    intermediate (SURVEY.md §8c expected 1e-2..5e-2)."""
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    from lavie_amd.scheduling_ddpm import DDPMScheduler
+    net, _ = full
+    fx = G.load("ddpm_50step.pt")
+    pipe = VideoGenPipeline(unet=net, scheduler=DDPMScheduler())
+    seen = {}
+    out = pipe(prompt_embeds=fx["prompt"], negative_prompt_embeds=fx["negative"], latents=fx["latents"], height=64, width=64,
+               video_length=16, num_inference_steps=fx["steps"], guidance_scale=fx["guidance_scale"],
+               generator=torch.Generator().manual_seed(fx["noise_seed"]), output_type="latent",
+               callback=lambda i, t, x: seen.__setitem__(i, x.float().cpu().clone())).video.float().cpu()
+    errs = {i: rel_l2(seen[i], ref) for i, ref in fx["kept"].items()}
+    cos = torch.nn.functional.cosine_similarity(out.flatten(), fx["y"].flatten(), dim=0).item()
+    print("trajectory rel-L2 per kept step:", {i: f"{e:.2e}" for i, e in errs.items()}, "final cosine", cos)
+    assert torch.equal(out, seen[49])
+    assert max(errs.values()) < 2e-2, errs
+    assert rel_l2(out, fx["y"]) < 3e-2 and cos > 0.999
+
+
+def test_transformer3d_reference_fixture_base_width():
+    """tests/golden/transformer3d.pt — the reference's Transformer3DModel at the base model's first-level width
+    (C = 320, head dim 40, per-frame GroupNorm eps 1e-6, order spatial -> text -> temporal -> FF) — through
+    lavie_unet_transformer_forward; the fixture's block weights replace those of a two-level model's first block."""
+    from lavie_amd import ops, spec
+    from lavie_amd.config import UNetConfig
+    fx = G.load("transformer3d.pt")
+    cfg = UNetConfig(block_out_channels=(320, 640), attn_levels=(True, False))
+    sd = G.synth16(spec.param_shapes(cfg), 3)
+    prefix = "down_blocks.0.attentions.0"
+    blk = G.synth16(fx["shapes"], fx["seed"], prefix + ".")
+    assert set(blk) == {k for k in sd if k.startswith(prefix + ".")}
+    sd.update(blk)
+    net = build(sd, sample_size=8, block_out_channels=(320, 640), cross_attention_dim=768,
+                down_block_types=("CrossAttnDownBlock3D", "DownBlock3D"), up_block_types=("UpBlock3D", "CrossAttnUpBlock3D"))
+    x = fx["x"].float()
+    b, c, f, h, w = x.shape
+    y = ops.unet_transformer(net, prefix, h16(to_rows(x)), h16(fx["ctx"]), b, f, h, w)
+    assert rel_l2(from_rows(y.float().cpu(), b, f, h, w), fx["y"]) < TOL_BLOCK
+
+
 def test_pipeline_call_surface(small):
     """__call__ with prompt_embeds / latents / CPU generator / callback, output_type='latent'; deterministic."""
     from lavie_amd.pipeline_videogen import VideoGenPipeline
@@ -311,6 +357,40 @@ def test_pipeline_call_surface(small):
     assert rel_l2(outs[0], ref) < 3e-2
     with pytest.raises(ValueError):
         pipe(prompt="a horse", height=64, width=64)            # no text encoder attached
+
+
+def test_pipeline_without_guidance(small):
+    """guidance_scale <= 1: do_classifier_free_guidance is False (pipeline_videogen.py:626) — the model batch is the
+    latents alone (:666), eps is used as it is (:678) and no negative embeddings are needed; against the oracle UNet
+    driven by the same loop arithmetic, and equal to guidance 1.0 + epsilon with identical text halves."""
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    from oracle import unet_fp32 as O
+    from oracle.ddpm import DDPMSchedule
+    net, sd = small
+    pipe = VideoGenPipeline(unet=net)
+    g = torch.Generator().manual_seed(19)
+    pe = torch.randn(2, 77, 128, generator=g)                      # two prompts in one call
+    lat = torch.randn(2, 4, 4, 8, 8, generator=g)
+    out = pipe(prompt_embeds=pe, latents=lat, height=64, width=64, video_length=4, num_inference_steps=4,
+               guidance_scale=1.0, generator=torch.Generator().manual_seed(5), output_type="latent").video.float().cpu()
+    sch = DDPMSchedule()
+    sch.set_timesteps(4)
+    gen = torch.Generator().manual_seed(5)
+    x = lat.clone()
+    for t in sch.timesteps:
+        eps = O.unet_forward(sd, x.half().float(), t, pe.half().float(), ocfg_small())
+        x = sch.step(eps, t, x, torch.randn(lat.shape, generator=gen) if t > 0 else None)
+    assert rel_l2(out, x) < 3e-2
+    # a list of generators, one per latent (:499-504): each latent's noise comes from its own generator
+    gl = lambda: [torch.Generator().manual_seed(31), torch.Generator().manual_seed(32)]
+    o2 = pipe(prompt_embeds=pe, latents=lat, height=64, width=64, video_length=4, num_inference_steps=4, guidance_scale=1.0,
+              generator=gl(), output_type="latent").video.float().cpu()
+    o1 = pipe(prompt_embeds=pe[1:], latents=lat[1:], height=64, width=64, video_length=4, num_inference_steps=4,
+              guidance_scale=1.0, generator=[torch.Generator().manual_seed(32)], output_type="latent").video.float().cpu()
+    assert rel_l2(o2[1:], o1) < 5e-3                               # batch 2 vs batch 1: other tile choices, same noise
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe, latents=lat, height=64, width=64, video_length=4, num_inference_steps=4,
+             guidance_scale=1.0, generator=[torch.Generator()], output_type="latent")
 
 
 def test_pipeline_ddim_scheduler(small):

@@ -175,3 +175,29 @@ def test_interp_ddim_loop_rejects_unsupported_modes(full):
         d.ddim_sample_loop(net.forward_with_cfg, z.shape, z, clip_denoised=True)
     with pytest.raises(NotImplementedError):
         d.ddim_sample_loop(net.forward_with_cfg, z.shape, z, clip_denoised=False, mask=z)
+
+
+def test_interp_full_size_properties(full):
+    """BASELINE.json configs[3] at its full size (909 M parameters, F = 61, latent 40x64, guidance batch 2) through
+    size-independent properties, as test_full_size_properties does for configs[1]: bit-reproducible, identical halves give
+    bit-identical halves, a batch-1 call (other tile / split-K choices) agrees, finite; the F = 61 temporal tile and the
+    2 x 2560-key sparse-causal attention run at production size."""
+    net, _, _ = full
+    g = torch.Generator().manual_seed(61)
+    x1 = torch.randn(1, 8, 61, 40, 64, generator=g).half()
+    c1 = torch.randn(1, 77, 768, generator=g).half()
+    x2, c2 = torch.cat([x1, x1]).cuda(), torch.cat([c1, c1]).cuda()
+    y2 = net(x2, 500, encoder_hidden_states=c2).sample
+    y2b = net(x2, 500, encoder_hidden_states=c2).sample
+    assert torch.equal(y2, y2b)
+    assert torch.isfinite(y2).all()
+    assert torch.equal(y2[0], y2[1])
+    y1 = net(x1.cuda(), 500, encoder_hidden_states=c1.cuda()).sample
+    assert rel_l2(y1[0], y2[0]) < 5e-3
+    y3 = net(x2, 20, encoder_hidden_states=c2).sample
+    assert rel_l2(y3, y2) > 1e-2
+    # editing the last frame changes the answer (no stale buffers) and keeps the two halves bit-identical
+    x2e = x2.clone()
+    x2e[:, :, 60] += 1.0
+    y2e = net(x2e, 500, encoder_hidden_states=c2).sample
+    assert torch.equal(y2e[0], y2e[1]) and rel_l2(y2e, y2) > 1e-4

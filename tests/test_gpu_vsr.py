@@ -213,3 +213,35 @@ def test_pingpong_256_wide_tile_bit_identical():
     assert torch.equal(outs[0], outs[1])
     ref = F.conv2d(x.float(), wt.float(), cb.cpu(), padding=1).permute(0, 2, 3, 1).reshape(-1, c)
     assert rel_l2(outs[0], ref) < TOL_OP
+
+
+def test_vsr_production_shape_properties():
+    """The VSR UNet at the size vsr/sample.py runs it (691 M parameters, one 8-frame chunk of 320x512 latents, guidance
+    batch 2; ~31 GB workspace) through size-independent properties: bit-reproducible, identical halves give bit-identical
+    halves, finite, timestep / noise-level sensitive.  Also the shorter last chunk (F = 5: 61 = 7 x 8 + 5) right after it
+    on the same handle: the per-F tables are cached, the answer is reproducible after switching back and forth."""
+    from lavie_amd import spec, weights
+    from lavie_amd.config import VSR_CONFIG
+    from lavie_amd.vsr import UNet3DVSRModel
+    sd = weights.synth_state_dict(spec.param_shapes(VSR_CONFIG), 0)
+    net = UNet3DVSRModel(init_weights=False, sample_size=128, down_temporal_idx=(0, 1, 2, 3), mid_temporal=True,
+                         up_temporal_idx=(0, 1, 2, 3))
+    net.load_state_dict({k: v.half() for k, v in sd.items()})
+    del sd
+    net = net.to("cuda", torch.float16)
+    g = torch.Generator().manual_seed(8)
+    x1 = torch.randn(1, 4, 8, 320, 512, generator=g).half()
+    l1 = torch.randn(1, 3, 8, 320, 512, generator=g).half()
+    c1 = torch.randn(1, 77, 1024, generator=g).half()
+    x, low, ctx = torch.cat([x1, x1]).cuda(), torch.cat([l1, l1]).cuda(), torch.cat([c1, c1]).cuda()
+    labels = torch.tensor([20, 20])
+    y = net(x, 500, low, encoder_hidden_states=ctx, class_labels=labels).sample
+    assert torch.isfinite(y).all() and torch.equal(y[0], y[1])
+    y5 = net(x[:, :, :5], 500, low[:, :, :5], encoder_hidden_states=ctx, class_labels=labels).sample      # last chunk: F = 5
+    assert torch.isfinite(y5).all() and torch.equal(y5[0], y5[1])
+    yb = net(x, 500, low, encoder_hidden_states=ctx, class_labels=labels).sample
+    assert torch.equal(y, yb)
+    y5b = net(x[:, :, :5], 500, low[:, :, :5], encoder_hidden_states=ctx, class_labels=labels).sample
+    assert torch.equal(y5, y5b)
+    assert rel_l2(net(x, 20, low, encoder_hidden_states=ctx, class_labels=labels).sample, y) > 1e-3
+    assert rel_l2(net(x, 500, low, encoder_hidden_states=ctx, class_labels=torch.tensor([300, 300])).sample, y) > 1e-4

@@ -91,7 +91,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.lavie_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.lavie_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_relpos_buckets_host_function():
@@ -180,11 +180,45 @@ def test_ddim_scheduler_matches_oracle_and_fused_form():
             x0 = k_x * x - k_e * eps
             fused = c0 * x0 + ct * x + sigma * z
             assert torch.allclose(fused, want, rtol=1e-4, atol=1e-5), (t, eta)
+    # the other prediction types (vendored step :356-363) in step() and in the fused five-coefficient form, and the
+    # frozen outputs of the vendored class itself (tests/golden/ddim_steps.pt)
+    for kind in ("v_prediction", "sample"):
+        psch, posch = DDIMScheduler(prediction_type=kind), DDIMSchedule(prediction_type=kind)
+        psch.set_timesteps(50)
+        posch.set_timesteps(50)
+        for t in [int(v) for v in psch.timesteps]:           # every timestep can take a step
+            eta = 0.3 if t % 40 == 1 else 0.0
+            x, m, z = (torch.randn(1, 4, 2, 8, 8, generator=g) for _ in range(3))
+            want = posch.step(m, t, x, eta=eta, noise=z)
+            got = psch.step(m, t, x, eta=eta, variance_noise=z if eta > 0 else None).prev_sample
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+            k_x, k_m, c0, ct, sigma = psch.coefficients(t, eta)
+            fused = c0 * (k_x * x - k_m * m) + ct * x + sigma * z
+            assert torch.allclose(fused, want, rtol=1e-4, atol=1e-5), (kind, t, eta)
+    import golden_util as G
+    for c in G.load("ddim_steps.pt")["prediction_cases"]:
+        psch = DDIMScheduler(prediction_type=c["kind"])
+        psch.set_timesteps(50)
+        got = psch.step(c["model_output"], c["t"], c["x"], eta=c["eta"], variance_noise=c["noise"] if c["eta"] > 0 else None)
+        rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+        # 5e-5: at t = 1 the `sample` branch divides by sqrt(1 - abar) = 1e-2 and the vendored class rounds in fp32
+        assert rel(got.prev_sample, c["prev"]) < 5e-5 and rel(got.pred_original_sample, c["x0"]) < 5e-5
+    for t in [int(v) for v in sch.timesteps]:                # stock spacing: all 50 timesteps lie inside the alpha table
+        sch.coefficients(t, 0.0)
     vsr = DDIMScheduler(timestep_spacing="vsr_linspace")
     ovsr = DDIMSchedule(timestep_spacing="vsr_linspace")
     vsr.set_timesteps(50)
     ovsr.set_timesteps(50)
     assert [int(t) for t in vsr.timesteps] == ovsr.timesteps
+    # ... whose first timestep (1001) is past the 1000-entry table, in the vendored text as in the mirror: a clear error
+    with pytest.raises(ValueError, match="outside"):
+        vsr.coefficients(int(vsr.timesteps[0]))
+    with pytest.raises(ValueError, match="outside"):
+        vsr.step(torch.zeros(1), int(vsr.timesteps[0]), torch.zeros(1))
+    for t in [int(v) for v in vsr.timesteps[1:]]:
+        vsr.coefficients(t)
+    with pytest.raises(ValueError):
+        DDIMScheduler(prediction_type="flow")
     with pytest.raises(ValueError):
         DDIMScheduler().coefficients(981)                # set_timesteps not called
     with pytest.raises(NotImplementedError):

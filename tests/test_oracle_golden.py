@@ -72,6 +72,20 @@ def test_ddpm_three_steps(full_sd):
     assert rel_l2(got, fx["y"]) < 1e-4
 
 
+def test_ddpm_trajectory_first_ten_steps(full_sd):
+    """oracle.ddpm against the 50-step reference-loop fixture (make_golden_traj.py: the loop restated from
+    pipeline_videogen.py:662-689 around the imported reference UNet, its own fp32-tensor DDPM step, noise from a CPU
+    generator seeded as the pipeline's `generator=`); the first 10 of the 50 steps keep the CPU suite short — the GPU
+    test walks all 50."""
+    fx = G.load("ddpm_50step.pt")
+    gen = torch.Generator().manual_seed(fx["noise_seed"])
+    noises = [torch.randn(fx["latents"].shape, generator=gen) for _ in range(10)]
+    fn = lambda x, t, c: O.unet_forward(full_sd, x, t, c)
+    got = cfg_denoise_loop(fn, fx["latents"], fx["prompt"].float(), fx["negative"].float(), noises,
+                           num_steps=fx["steps"], guidance_scale=fx["guidance_scale"], max_steps=10)
+    assert rel_l2(got, fx["kept"][9]) < 1e-4
+
+
 def test_ddim_steps_match_reference_fixture():
     """oracle/ddim.py against outputs of the reference's vendored DDIMScheduler (tests/golden/ddim_steps.pt)."""
     from oracle.ddim import DDIMSchedule
@@ -91,6 +105,12 @@ def test_ddim_steps_match_reference_fixture():
     for t in ch["timesteps"]:
         x = sch.step(torch.tanh(x * 0.7 + 0.01 * t / 1000.0), t, x)
     assert rel_l2(x, ch["y"]) < 1e-6
+    for c in fx["prediction_cases"]:                 # v_prediction / sample branches of the vendored step (:356-363)
+        psch = DDIMSchedule(prediction_type=c["kind"])
+        psch.set_timesteps(50)
+        got = psch.step(c["model_output"], c["t"], c["x"], eta=c["eta"], noise=c["noise"])
+        # 5e-5: at t = 1 the `sample` branch divides by sqrt(1 - abar) = 1e-2 and the vendored class rounds in fp32
+        assert rel_l2(got, c["prev"]) < 5e-5, (c["kind"], c["t"], c["eta"])
 
 
 # ------------------------------------------------------------------ frame-interpolation model

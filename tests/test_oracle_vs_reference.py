@@ -138,6 +138,17 @@ def test_ddim_oracle_matches_vendored_reference_scheduler():
         for eta in (0.0, 1.0):
             want = ref.step(eps, t, x, eta=eta, variance_noise=z if eta > 0 else None).prev_sample
             assert rel_l2(sch.step(eps, t, x, eta=eta, noise=z), want) < 1e-6
+    for kind in ("v_prediction", "sample"):          # the other branches of the vendored step (:356-363)
+        pref = refimport.load_vsr_ddim()(num_train_timesteps=1000, beta_start=1e-4, beta_end=0.02, beta_schedule="linear",
+                                         clip_sample=False, set_alpha_to_one=False, steps_offset=1, prediction_type=kind)
+        pref.set_timesteps(50)
+        psch = DDIMSchedule(timestep_spacing="vsr_linspace", prediction_type=kind)
+        psch.set_timesteps(50)
+        for t in psch.timesteps[1::7]:
+            x, m, z = (torch.randn(2, 4, 3, 8, 8, generator=g) for _ in range(3))
+            for eta in (0.0, 1.0):
+                want = pref.step(m, t, x, eta=eta, variance_noise=z if eta > 0 else None).prev_sample
+                assert rel_l2(psch.step(m, t, x, eta=eta, noise=z), want) < 1e-6, (kind, t, eta)
 
 
 # ------------------------------------------------------------------ frame-interpolation model

@@ -54,7 +54,12 @@ def _worker(rank, world, port, num_prompts, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("num_prompts", [4, 5])
+def test_run_prompts_rejects_zero_prompts_on_every_rank():
+    with pytest.raises(ValueError):
+        prompt_dp.run_prompts(lambda i: torch.zeros(1, 2), 0)
+
+
+@pytest.mark.parametrize("num_prompts", [4, 5, 1])        # 1: fewer prompts than ranks — rank 1 idles, nobody hangs
 def test_two_ranks_gloo(num_prompts):
     port = _free_port()
     mgr = mp.Manager()
