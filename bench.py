@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: video-latents/sec of the LaVie base T2V denoising path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: spawns its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch of synthetic input = ONE fully denoised video
@@ -19,7 +19,8 @@ Extra objects on that line:
                     instrumented forward after the timed region (an event pair costs ~11 us of stream time)
   roofline_temporal the temporal-attention core (HBM-bound): algorithmic bytes 4*tokens*C*2 per launch / duration
   kernel_breakdown  every kernel class, from one extra instrumented UNet forward after the timed region
-  cpu_baseline      the fp32 CPU oracle (kind "port") timed on this host's cores on a bounded sample
+  cpu_baseline      the fp32 CPU oracle (kind "port") on this host's cores: 1 warm-up + 2 timed full CFG denoise steps
+                    (BASELINE.md §4), extrapolated x50
 """
 import argparse
 import ctypes
@@ -80,25 +81,112 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(sd_fp32, sample_frames, threads):
-    """Oracle (fp32, all host cores) on a bounded sample: ONE CFG UNet forward at batch 2 with `sample_frames`
-    of the 16 frames at the full 40x64 latent.  Every op except the (negligible, 0.1 %) temporal-attention core
-    is linear in the frame count, so one video-latent = 50 steps x (16 / sample_frames) x this time."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd_fp32, threads, timed_steps=2):
+    """the fp32 CPU oracle (kind "port": proven equal to the imported reference in the build container)
+    on this host's cores, the SAME workload as the GPU run — full 16 frames at the 40x64 latent, CFG batch 2 — driven
+    through the loop of pipeline_videogen.py:662-689: 1 warm-up iteration, then `timed_steps` consecutive iterations of
+    (UNet forward at batch 2 + CFG combine + DDPM step), extrapolated x50 (every iteration runs the same graph)."""
     from oracle import unet_fp32 as O
+    from oracle.ddpm import DDPMSchedule
     torch.set_num_threads(threads)
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(2, 4, sample_frames, LAT_H, LAT_W, generator=g)
-    ctx = torch.randn(2, CTX_LEN, CTX_DIM, generator=g)
-    t0 = time.perf_counter()
+    pe, ne, lat = synth_inputs(0, "cpu")
+    ctx = torch.cat([ne, pe])
+    sch = DDPMSchedule()
+    sch.set_timesteps(DDPM_STEPS)
+    gen = torch.Generator().manual_seed(3000)
+    x = lat.clone()
+    times = []
     with torch.no_grad():
-        O.unet_forward(sd_fp32, x, 500, ctx)
-    dt = time.perf_counter() - t0
-    per_video = dt * (FRAMES / sample_frames) * DDPM_STEPS
+        for i, t in enumerate(sch.timesteps[:1 + timed_steps]):
+            t0 = time.perf_counter()
+            eps = O.unet_forward(sd_fp32, torch.cat([x, x]), t, ctx)
+            guided = eps[0:1] + GUIDANCE * (eps[1:2] - eps[0:1])
+            x = sch.step(guided, t, x, torch.randn(x.shape, generator=gen))
+            times.append(time.perf_counter() - t0)
+    per_step = sum(times[1:]) / timed_steps
+    per_video = per_step * DDPM_STEPS
     return {"value": 1.0 / per_video, "unit": "video-latents/s", "cores": torch.get_num_threads(), "kind": "port",
-            "seconds_sampled": dt,
-            "sample": f"one fp32 CFG UNet forward, batch 2, {sample_frames} of {FRAMES} frames at 40x64 latent "
-                      f"({dt:.1f} s), extrapolated x{FRAMES // sample_frames} frames x{DDPM_STEPS} DDPM steps",
-            "host_cpu_count": os.cpu_count()}
+            "seconds_per_step": per_step, "seconds_sampled": sum(times), "step_seconds": [round(v, 2) for v in times],
+            "sample": f"1 warm-up + {timed_steps} timed consecutive CFG denoise steps (fp32 UNet forward at batch 2, all {FRAMES} "
+                      f"frames, 40x64 latent, + CFG + DDPM step) = {sum(times[1:]):.1f} s timed; x{DDPM_STEPS} steps extrapolated "
+                      f"to {per_video:.0f} s per video-latent",
+            "host_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(), "cpu_model": cpu_model_string(),
+            "torch_version": torch.__version__}
+
+
+# ------------------------------------------------------------------ self-launch: python bench.py --gpus N without a launcher
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh rank processes (one per GPU) with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly as torch.distributed.run would, wait for them, relay rank 0's
+    JSON line and return non-zero if any rank failed.  The parent has not touched the GPU (nothing before this point
+    initialises HIP) and never does: the children are ordinary child processes, not an exec of this one."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: rank(s) failed: {bad}\n")
+        return 1
+    return 0
+
+
+def launcher_selftest(rank, world, args):
+    """--selftest-launcher (CPU, gloo; tests/test_bench_launcher.py): the distributed plumbing of the real run — init,
+    weight broadcast, per-rank work, latent all_gather, barrier, MAX-over-ranks timing, one JSON line from rank 0 — around
+    a stand-in for the denoiser.  Its line is labelled as such and carries no metric."""
+    from lavie_amd import prompt_dp
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    shapes = {"w": (8, 4), "b": (8,)}
+    sd = {k: torch.full(v, 0.5) for k, v in shapes.items()} if rank == 0 else None
+    views = prompt_dp.broadcast_weights(shapes, sd, "cpu", dtype=torch.float32)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    outs = [views["w"].sum().reshape(1, 1) * (rank + world * i + 1) for i in range(args.steps)]
+    gathered = prompt_dp.gather_latents(torch.cat(outs), [args.steps] * world)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "data": "stub (no denoiser ran; not a measurement)", "n_gpus": world,
+                          "ranks_seen": len(gathered), "steps": args.steps,
+                          "values": [float(v) for g in gathered for v in g.flatten()], "backend": "gloo"}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -107,17 +195,23 @@ def main():
     ap.add_argument("--steps", type=int, default=3, help="timed video-latents per GPU")
     ap.add_argument("--warmup", type=int, default=1, help="untimed video-latents per GPU")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample-frames", type=int, default=8, help="frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CFG denoise steps of the CPU baseline after 1 warm-up (0 = skip)")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)      # CPU test of the rank plumbing
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = cgroup/affinity share)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline instrumentation")
     ap.add_argument("--ddpm-steps", type=int, default=DDPM_STEPS, help=argparse.SUPPRESS)   # debugging only
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become one (before anything touches the GPU)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if args.selftest_launcher:
+        raise SystemExit(launcher_selftest(rank, world, args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists); build with __graft_entry__.build() and run on the GPU box")
     # LAVIE_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): every rank uses device 0 and the collectives go
@@ -262,9 +356,9 @@ def main():
                              tflops=(r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 and r["flops"] > 0 else None),
                              gbs=(r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else None)) for r in rows]}
 
-    if rank == 0 and world == 1 and args.cpu_sample_frames > 0:
-        result["cpu_baseline"] = cpu_baseline({k: v.float() for k, v in sd32.items()}, args.cpu_sample_frames,
-                                              args.cpu_threads or host_cores())
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        result["cpu_baseline"] = cpu_baseline({k: v.float() for k, v in sd32.items()}, args.cpu_threads or host_cores(),
+                                              args.cpu_steps)
 
     if rank == 0:
         print(json.dumps(result))

@@ -158,6 +158,9 @@ int lavie_debug_temporal_budget(int bytes);
 /* Diagnostic: per-wave phase-segment cycle sums [8 waves][16] of the last halo-patch conv launched in stamp mode
  * (lavie_debug_force_tile(0x75)); layout in igemm_patch.hip. */
 int lavie_debug_patch_stamps(unsigned long long* out128);
+/* Diagnostic: per-wave segment cycle sums [8 waves][32] of the last persistent ping-pong GEMM launched in stamp mode
+ * (lavie_debug_force_tile(0x37)); layout in igemm_ppx.hip. */
+int lavie_debug_ppx_stamps(unsigned long long* out256);
 int lavie_profile_begin(unsigned mask, int max_events);
 int lavie_profile_end(void* stream, long long* launches_host, double* ms_host, double* flops_host, double* bytes_host);
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "lavie_debug_attention_qt": (c_int, [c_int]),
     "lavie_debug_temporal_budget": (c_int, [c_int]),
     "lavie_debug_patch_stamps": (c_int, [c_void_p]),
+    "lavie_debug_ppx_stamps": (c_int, [c_void_p]),
     "lavie_profile_begin": (c_int, [C.c_uint, c_int]),
     "lavie_profile_end": (c_int, [c_void_p, C.POINTER(c_ll), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),

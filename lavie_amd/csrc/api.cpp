@@ -228,6 +228,11 @@ int lavie_debug_force_splits(int s) { igemm_force_splits(s); return 0; }
 int lavie_debug_conv_tap_major(int on) { g_tap_major = on; return 0; }
 int lavie_debug_attention_qt(int qt) { attention_force_qt(qt); return 0; }
 int lavie_debug_temporal_budget(int bytes) { temporal_set_budget(bytes); return 0; }
+int lavie_debug_ppx_stamps(unsigned long long* out256) {
+    LAVIE_CHECK(out256, "ppx_stamps: null output");
+    return igemm_ppx_read_stamps(out256);
+}
+
 int lavie_debug_patch_stamps(unsigned long long* out128) {
     LAVIE_CHECK(out128, "patch_stamps: null output");
     return igemm_patch_read_stamps(out128);

@@ -63,6 +63,11 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
 // 160x320 two-group ping-pong kernel (igemm_pp.hip); EPI_LINEAR only, N %% 320 == 0, the caller runs the split-K reduce.
 int launch_igemm_pp(const IgemmParams& p, bool gather, hipStream_t stream);
 int launch_igemm_pp_geglu(const IgemmParams& p, hipStream_t stream);   // 160x256 variant, GEGLU epilogue, N %% 256 == 0
+// Persistent ping-pong kernel (igemm_ppx.hip): plain A rows, no split-K; at most 256 workgroups walk the output tiles with
+// the LDS-DMA stream running across tile boundaries.  EPI_LINEAR (N %% 320 == 0 or N %% 256 == 0) and EPI_GEGLU (N %% 256 == 0).
+bool igemm_ppx_eligible(const IgemmParams& p, int epilogue);
+int launch_igemm_ppx(const IgemmParams& p, int epilogue, hipStream_t stream);
+int igemm_ppx_read_stamps(unsigned long long* out);   // diagnostic stamp build (mode 0x37): [8 waves][32] cycle sums of workgroup 0
 // 320x160 halo-patch 3x3 conv kernel (igemm_patch.hip): stride 1, 9-tap segments only; the caller runs the split-K reduce.
 bool igemm_patch_eligible(const IgemmParams& p);
 int launch_igemm_patch(const IgemmParams& p, hipStream_t stream);
@@ -78,7 +83,8 @@ int igemm_rowstat_cols(int M, int N, int nk);
 int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len, float eps, float* out, hipStream_t stream);
 // Low nibble: 0 = automatic kernel / tile choice, 1 = 128-row kernel with the widest tile,
 // 3 = 160x320 ping-pong kernel whenever N %% 320 == 0, 4 = automatic but never the ping-pong kernel (A/B timing),
-// 5 = halo-patch conv kernel whenever the conv is eligible, 6 = automatic but never the halo-patch kernel.
+// 5 = halo-patch conv kernel whenever the conv is eligible, 6 = automatic but never the halo-patch kernel,
+// 7 = persistent ping-pong kernel for every eligible plain GEMM, 8 = automatic but never the persistent kernel.
 // High nibble: diagnostic ablation build of the forced kernel (results wrong).
 void igemm_force_tile(int mode);
 void igemm_force_splits(int s);   // 0 = automatic

@@ -379,7 +379,10 @@ static bool patch_fits(int M, int N, int nk, int s) {
     const double r = (double)(M / 320) * (N / 160) * s / 256.0;
     return r / ceil(r) >= 0.85;
 }
-static bool patch_allowed() { const int lo = g_force_tile & 0xF; return lo == 0 || lo == 5; }
+static bool patch_allowed() { const int lo = g_force_tile & 0xF; return lo == 0 || lo == 5 || lo == 8; }
+
+static int plan_splits(int M, int N, int nk, int epilogue, bool plain);
+static bool ppx_plan_shape(int M, int N, int nk, int epilogue);
 
 int igemm_plan_splits_gather(const IgemmParams& p) {
     if (g_force_splits == 0 && patch_allowed()) {
@@ -389,11 +392,14 @@ int igemm_plan_splits_gather(const IgemmParams& p) {
             if (patch_fits(p.M, p.N, p.nk, s) && igemm_patch_eligible(q)) return s;
         }
     }
-    return igemm_plan_splits(p.M, p.N, p.nk, EPI_LINEAR);
+    return plan_splits(p.M, p.N, p.nk, EPI_LINEAR, false);
 }
 
-int igemm_plan_splits(int M, int N, int nk, int epilogue) {
+int igemm_plan_splits(int M, int N, int nk, int epilogue) { return plan_splits(M, N, nk, epilogue, true); }
+
+static int plan_splits(int M, int N, int nk, int epilogue, bool plain) {
     if (epilogue != EPI_LINEAR || N % 64 != 0) return 1;
+    if (plain && g_force_splits == 0 && ppx_plan_shape(M, N, nk, epilogue)) return 1;     // the persistent kernel never splits K
     if (g_force_splits > 0) return g_force_splits <= nk ? g_force_splits : 1;
     if (const int s = pp_plan(M, N, nk, epilogue)) return s;
     const long blocks = (long)cdiv(M, 128) * cdiv(N, 160);
@@ -408,6 +414,24 @@ int igemm_plan_splits(int M, int N, int nk, int epilogue) {
         if (cost < best * 0.93) { best = cost; best_s = s; }
     }
     return best_s;
+}
+
+// ---- persistent ping-pong kernel (igemm_ppx.hip) for plain GEMMs: forced (mode 7) or by the measured rule
+static bool ppx_plan_shape(int M, int N, int nk, int epilogue) {
+    const int lo = g_force_tile & 0xF;
+    if (M % 160 != 0 || nk < 5 || (epilogue == EPI_GEGLU ? N % 256 != 0 : (N % 320 != 0 && N % 256 != 0))) return false;   // = igemm_ppx_eligible's shape part
+    if (lo == 7) return true;
+    if (lo != 0 && lo != 6) return false;
+    // Measured (tools/check_ppx.py, profiles/r02_ppx_shapes.txt): the persistent kernel wins where the K loop is short and
+    // every CU gets at least one whole tile — the L0 GEMMs with K = 320 (N = 320: -14 .. -23 %, QKV -7 %, GEGLU -10 %) and
+    // the L1 K = 640 linear ones (-3 .. -10 %); it loses on long K loops (the one-tile kernels' second workgroup per CU
+    // hides their epilogue better) and on under-filled grids (M = 5120: 128 tiles).
+    const long tiles = (long)(M / 160) * (N / pp_bn(N));
+    if (tiles < 256 || nk > 10) return false;
+    return epilogue == EPI_LINEAR || nk <= 5;
+}
+static bool ppx_plan(const IgemmParams& p, int epilogue) {
+    return p.splits == 1 && igemm_ppx_eligible(p, epilogue) && ppx_plan_shape(p.M, p.N, p.nk, epilogue);
 }
 
 template <int WM, int WN, int MT, int NT, int NSTAGE, bool GATHER, int EPI, int ABL = 0>
@@ -471,6 +495,7 @@ int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len
 // Columns per row-statistics slot (= the wave tile width 16*NT) launch_igemm uses for a plain, unsplit EPI_LINEAR
 // GEMM; two waves share a tile's columns.
 int igemm_rowstat_cols(int M, int N, int nk) {
+    if (ppx_plan_shape(M, N, nk, EPI_LINEAR)) return pp_bn(N) / 4;                                              // persistent ping-pong wave tile
     if ((g_force_tile & 0xF) == 3 ? N % 320 == 0 : (pp_plan(M, N, nk, EPI_LINEAR) == 1)) return pp_bn(N) / 4;   // ping-pong wave tile
     return igemm_pick_bn(M, N, 1) / 2;
 }
@@ -485,7 +510,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     LAVIE_CHECK(!(p.rowstat_out || p.ln_stats) || (p.splits == 1 && !gather), "igemm: LayerNorm folding needs a plain, unsplit GEMM");
     LAVIE_CHECK(p.splits >= 1 && p.splits <= p.nk && (p.splits == 1 || (p.slab && epilogue == EPI_LINEAR)),
                 "igemm: bad split-K setup (splits=%d)", p.splits);
-    const int lo = g_force_tile & 0xF;
+    const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);      // 8 = automatic without the persistent kernel
     auto reduce_splits = [&]() -> int {          // fixed-order sum of the split-K slabs + bias / residual / rounding
         if (p.splits > 1) {
             const long total = (long)p.M * (p.N / 4);
@@ -498,12 +523,14 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         LAVIE_CHECK(p.N % 128 == 0, "igemm: GEGLU needs N %% 128 == 0 (N=%d)", p.N);
         LAVIE_CHECK(!p.R && !p.bias2, "igemm: GEGLU epilogue takes no residual / per-batch bias");
         LAVIE_CHECK(!gather, "igemm: GEGLU epilogue is only built for plain A rows");
+        if (ppx_plan(p, epilogue)) return launch_igemm_ppx(p, epilogue, stream);
         // 160x256 ping-pong variant: same grid rule as the 160x320 kernel, from g_geglu_pp_min_nk K-tiles on
         const double r = (double)cdiv(p.M, 160) * (p.N / 256) / 256.0;
         if (p.N % 256 == 0 && (lo == 3 || ((lo == 0 || lo == 6) && p.nk >= g_geglu_pp_min_nk && r / ceil(r) >= 0.85)))
             return launch_igemm_pp_geglu(p, stream);
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
     }
+    if (!gather && ppx_plan(p, epilogue)) return launch_igemm_ppx(p, epilogue, stream);
     // halo-patch conv kernel: forced (mode 5) or whenever its grid rule holds at this split factor
     if (gather && igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits)))) {
         if (int rc = launch_igemm_patch(p, stream)) return rc;
@@ -540,9 +567,11 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
 }
 
 void igemm_pp_ablate(int a);
+void igemm_ppx_ablate(int a);
 void igemm_patch_set_stamp(int mode);
 void igemm_force_tile(int mode) {
     g_force_tile = mode;
+    igemm_ppx_ablate((mode & 0xF) == 7 ? mode >> 4 : 0);
     igemm_pp_ablate((mode & 0xF) == 3 ? mode >> 4 : 0);
     igemm_patch_set_stamp(mode == 0x75 ? 1 : mode == 0x85 ? 2 : mode == 0x95 ? 3 : mode == 0xA5 ? 4 : mode == 0xB5 ? 5 : 0);
 }

@@ -22,3 +22,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "reference" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _forced_gemm_kernel():
+    """LAVIE_FORCE_TILE=<mode> runs the GPU tests with one GEMM kernel forced everywhere it is eligible
+    (lavie_debug_force_tile; e.g. 7 = the persistent ping-pong kernel): kernel choice must never change results."""
+    mode = os.environ.get("LAVIE_FORCE_TILE")
+    if mode:
+        from lavie_amd import _lib
+        _lib.load().lavie_debug_force_tile(int(mode, 0))
+    yield

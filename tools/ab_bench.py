@@ -19,7 +19,7 @@ def run(lib, steps):
     if mode:
         env["LAVIE_FORCE_TILE"] = mode
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1",
-                          "--cpu-sample-frames", "0"], env=env, capture_output=True, text=True)
+                          "--cpu-steps", "0"], env=env, capture_output=True, text=True)
     if out.returncode != 0:
         print(out.stderr[-2000:])
         raise SystemExit(f"bench.py failed with {lib}")
