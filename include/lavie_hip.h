@@ -221,6 +221,12 @@ int lavie_unet_set_param(lavie_unet_t h, const char* name, const void* data_f16,
 int lavie_unet_finalize(lavie_unet_t h, void* stream);
 /* Size the activation workspace for inputs up to [B, *, F, H, W] (allocates; not stream-ordered). */
 int lavie_unet_prepare(lavie_unet_t h, int B, int F, int H, int W, int ctx_len);
+/* Optional: the text keys / values of every transformer block (attention.py:177-178 on encoder_hidden_states, which the
+ * reference recomputes in every block of every denoising step, and once per frame: :364) computed ONCE for the context
+ * tensor `ctx` [B, ctx_len, cross_attention_dim] and kept in the handle.  Forwards called afterwards with the same `ctx`
+ * pointer, B and ctx_len read them instead of recomputing them; any other context is computed as usual.  The caller
+ * promises not to change the tensor's contents while it is cached; ctx = NULL drops the cache.  Needs lavie_unet_prepare. */
+int lavie_unet_cache_context(lavie_unet_t h, const void* ctx, int B, int ctx_len, void* stream);
 /* A/B switch (default on): fold every LayerNorm of the transformer blocks into the epilogues of the GEMM that
  * produces its input (row statistics) and the GEMM that consumes its output (gamma folded into the weights). */
 int lavie_unet_set_ln_fold(lavie_unet_t h, int on);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "lavie_unet_set_param": (c_int, [c_void_p, c_char_p, c_void_p, c_ll]),
     "lavie_unet_finalize": (c_int, [c_void_p, c_void_p]),
     "lavie_unet_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "lavie_unet_cache_context": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lavie_unet_set_ln_fold": (c_int, [c_void_p, c_int]),
     "lavie_unet_weight_bytes": (c_ll, [c_void_p]),
     "lavie_unet_workspace_bytes": (c_ll, [c_void_p]),

@@ -293,6 +293,11 @@ int lavie_unet_prepare(lavie_unet_t h, int B, int F, int Hh, int W, int ctx_len)
     return h->net.prepare(B, F, Hh, W, ctx_len);
 }
 
+int lavie_unet_cache_context(lavie_unet_t h, const void* ctx, int B, int ctx_len, void* stream) {
+    LAVIE_CHECK(h, "cache_context: null handle");
+    return h->net.cache_context(H(ctx), B, ctx_len, S(stream));
+}
+
 int lavie_unet_set_ln_fold(lavie_unet_t h, int on) {
     LAVIE_CHECK(h, "set_ln_fold: null handle");
     h->net.set_ln_fold(on != 0);

@@ -320,6 +320,288 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (round 2).  tools/attn_ablate.py put ~290 of the 565 us of L0 self-attention in the register-staged
+// load -> ds_write -> barrier chain: each tile's global loads had ONE tile of compute to come back in, and an L2 round
+// trip under load is longer than that even with three workgroups per CU.  Here K / V tiles go HBM / L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write), THREE tile buffers deep: tile t+2 is issued while tile t is
+// computed, waits are counted (vmcnt(pieces of one tile)), one barrier per tile.
+//  * LDS rows hold R 16-byte chunks, R * 16 = an odd multiple of 32 bytes (the conflict-free stride of the register-staged
+//    kernel), and a wave instruction writes 64 consecutive chunks, so rows are contiguous: the chunks a row has beyond
+//    the head's dh / 8 real ones are fetched from a 32-byte constant page — zeros, or {1, 0, ...} for the V chunk that
+//    carries the LSUM column of ones — by pointing those lanes' source address at it (the source address is per lane).
+//  * K columns past dh need no zeros: the Q fragment is zero there, and 0 * finite = 0.
+//  * every wave issues the same number of pieces per tile (R / 2; R is even), so one counted wait serves all.
+#ifndef ATT_DMA_OCC5
+#define ATT_DMA_OCC5 4      // waves per SIMD asked for at head dim 40 (128 VGPRs, 4 x 37 KiB of LDS per CU)
+#endif
+__device__ __attribute__((aligned(16))) half_t g_att_pad_page[16] = {(half_t)1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// NCH = dh / 8 = 16-byte chunks a key row really has (the model's head dims: 5, 10, 20); the row holds R >= NCH (+ 1 for the
+// LSUM column) chunks with R = 2 (mod 4); the MFMA loops still run over DHP = dh rounded up to 32 (K) / NDT 16-wide tiles (V)
+template <int NCH, bool LSUM>
+struct AttDmaTile {
+    static constexpr int DHP = (NCH * 8 + 31) / 32 * 32;
+    static constexpr int NEED = NCH + (LSUM ? 1 : 0);
+    static constexpr int R = NEED % 4 == 2 ? NEED : NEED + (6 - NEED % 4) % 4;      // smallest R >= NEED with R % 4 == 2
+    static constexpr int RS = R * 16;                                    // row stride: 32 B x odd
+    static constexpr int TILE_BYTES = ATT_KEYS * RS;                     // one of K / V = R KiB
+    static constexpr int PIECES = R / 2;                                 // 1-KiB pieces per wave and tile (K and V together: 2 R)
+    static constexpr int KS = DHP / 32, DT = DHP / 16, NDT = (NCH * 8 + 15) / 16;
+};
+
+template <int NCH, int QT, int NBUF, bool LSUM, bool SC>
+__global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void attention_dma_kernel(const AttnParams p) {
+    using T = AttDmaTile<NCH, LSUM>;
+    constexpr int R = T::R, RS = T::RS, PIECES = T::PIECES, NDT = T::NDT;
+    static_assert(R % 4 == 2 && R >= T::NEED && NDT * 32 <= RS, "row stride must be 32 B x odd and hold every output tile's columns");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // buffer b: K at b * 2 * TILE_BYTES, V right behind it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;       // 16-lane group
+    const int li = lane & 15;
+    const int head = blockIdx.y;
+    const int qb = blockIdx.z;
+    const int kvb = qb / p.kv_batch_div;
+    constexpr int dh = NCH * 8;
+    constexpr int nch = NCH;       // 16-byte chunks per key row that exist in HBM
+    const int q0 = blockIdx.x * (4 * QT * 16) + wave * (QT * 16);
+
+    // ---- Q fragments (B operand): lane holds Q[q = li][dims 32 ks + 8 g .. +7]
+    half8_t qf[QT][T::KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int q = q0 + qt * 16 + li;
+        q = q < p.Lq ? q : p.Lq - 1;
+        const half_t* qrow = p.q + ((size_t)qb * p.Lq + q) * p.ldq + head * dh;
+#pragma unroll
+        for (int ks = 0; ks < T::KS; ++ks) {
+            const int d = ks * 32 + g * 8;
+            if (d < dh) qf[qt][ks] = *reinterpret_cast<const half8_t*>(qrow + d);
+            else qf[qt][ks] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    const half_t* kbase = p.k + (SC ? (size_t)0 : (size_t)kvb * p.Lk * p.ldk) + head * dh;
+    const half_t* vbase = p.v + (SC ? (size_t)0 : (size_t)kvb * p.Lk * p.ldv) + head * dh;
+    const int sc_D = p.Lk >> 1;
+    const int sc_f = SC ? qb % p.sc_frames : 0;
+    const int sc_row0 = (qb - sc_f) * sc_D;
+    const int sc_row1 = (qb - (sc_f > 0 ? 1 : 0)) * sc_D - sc_D;      // row of key j >= D is sc_row1 + j
+    // ---- this wave's pieces: piece x of 2 R (0 .. R-1 = K, R .. 2R-1 = V) for x = wave, wave + 4, ...; lane l of piece x
+    // is chunk (x % R) * 64 + l of its operand's tile: key = chunk / R, column chunk = chunk % R
+    int pkey[PIECES], pch[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int x = wave + 4 * i;
+        const int chunk = (x % R) * 64 + lane;
+        pkey[i] = chunk / R;
+        pch[i] = chunk - pkey[i] * R;
+    }
+    const half_t* pad_zero = g_att_pad_page + 8;
+    const half_t* pad_one = g_att_pad_page;
+    auto issue_tile = [&](int key0, int buf) {
+        char* bbase = smem + buf * (2 * T::TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int x = wave + 4 * i;                       // wave-uniform
+            const bool is_v = x >= R;
+            int key = key0 + pkey[i];
+            key = key < p.Lk ? key : p.Lk - 1;                // keys past Lk: any finite row (their scores are masked)
+            size_t row;
+            if constexpr (SC) row = (size_t)(key < sc_D ? sc_row0 + key : sc_row1 + key);
+            else row = (size_t)key;
+            const half_t* src = is_v ? vbase + row * p.ldv + pch[i] * 8 : kbase + row * p.ldk + pch[i] * 8;
+            if (pch[i] >= nch) src = (is_v && LSUM && pch[i] == nch) ? pad_one : pad_zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(bbase + x * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 o[T::DT][QT];
+#pragma unroll
+    for (int dt = 0; dt < T::DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];      // running max (log2 units, scaled) and per-lane partial row sums
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+
+    const float sl2 = p.scale * 1.4426950408889634f;   // softmax scale folded with log2(e): p = exp2(s*sl2 - m)
+    const int ntile = cdiv(p.Lk, ATT_KEYS);
+
+    // the Q loads are consumed HERE, before any LDS-DMA is in flight: left to the compiler, the wait for them lands in
+    // front of the loop's first MFMA as vmcnt(0) and drains the K / V stream every tile
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < T::KS; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
+    issue_tile(0, 0);
+    if (ntile > 1) issue_tile(ATT_KEYS, 1 % NBUF);
+
+    int buf = 0;
+    for (int t = 0; t < ntile; ++t) {
+        // tile t has landed: all but the pieces of tile t+1 (when it exists) are done; then everybody's pieces
+        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // every wave has finished tile t-1: its buffer takes tile t+2 (NBUF = 3), i.e. two tiles of compute ahead
+        if (NBUF >= 3 && t + 2 < ntile) issue_tile((t + 2) * ATT_KEYS, (buf + 2) % NBUF);
+        const char* cK = smem + buf * (2 * T::TILE_BYTES);
+        const char* cV = cK + T::TILE_BYTES;
+
+        // ---- S^T[key, q] = K Q^T
+        f32x4 s[4][QT];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < T::KS; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const half8_t kf = *reinterpret_cast<const half8_t*>(cK + (kt * 16 + li) * RS + (ks * 4 + g) * 16);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
+            }
+        }
+
+        // ---- keys past Lk exist only in the last tile (wave-uniform branch)
+        const int kleft = p.Lk - t * ATT_KEYS;
+        if (kleft < ATT_KEYS) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + g * 4 + r >= kleft) s[kt][qt][r] = -INFINITY;
+        }
+
+        half8_t pb[2][QT];
+        // ---- online softmax per query column, deferred rescale (as the register-staged kernel)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt)
+                mx = fmaxf(mx, fmaxf(fmaxf(s[kt][qt][0], s[kt][qt][1]), fmaxf(s[kt][qt][2], s[kt][qt][3])));
+            {
+                const unsigned u = __float_as_uint(mx);
+                const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+                const unsigned v = __float_as_uint(mx);
+                const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+            }
+            const float mxs = mx * sl2;
+            if (__builtin_amdgcn_ballot_w64(mxs > m_run[qt] + RESCALE_THR) != 0) {
+                const float m_new = fmaxf(m_run[qt], mxs);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);   // first tile: exp2(-inf) = 0
+                m_run[qt] = m_new;
+                if constexpr (!LSUM) l_run[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < T::DT; ++dt) o[dt][qt] *= alpha;
+            }
+            const float nm = -m_run[qt];
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], sl2, nm));
+                    if constexpr (!LSUM) psum += e[r];
+                }
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const half2_t h0 = __builtin_convertvector((f32x2){e[0], e[1]}, half2_t);
+                const half2_t h1 = __builtin_convertvector((f32x2){e[2], e[3]}, half2_t);
+                pb[kt >> 1][qt][(kt & 1) * 4 + 0] = h0[0];
+                pb[kt >> 1][qt][(kt & 1) * 4 + 1] = h0[1];
+                pb[kt >> 1][qt][(kt & 1) * 4 + 2] = h1[0];
+                pb[kt >> 1][qt][(kt & 1) * 4 + 3] = h1[1];
+            }
+            if constexpr (!LSUM) l_run[qt] += psum;           // per-lane partial; reduced over g at the end
+        }
+
+        // ---- O^T[dim, q] += V^T P^T  (V^T fragments by hardware-transposed LDS reads)
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+#pragma unroll
+            for (int dt = 0; dt < T::DT; ++dt) {
+                if (dt < NDT) {
+                    const char* va = cV + (kt2 * 32 + g * 4 + (li >> 2)) * RS + (dt * 16 + (li & 3) * 4) * 2;
+                    const fp16x4_raw lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va));
+                    const fp16x4_raw hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va + 16 * RS));
+                    half8_t vf;
+                    __builtin_memcpy(&vf, &lo, 8);
+                    __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[kt2][qt], o[dt][qt], 0, 0, 0);
+                }
+            }
+        }
+        if (NBUF < 3) {       // two buffers (large heads): the buffer of tile t is free once every wave has finished it
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntile) issue_tile((t + 2) * ATT_KEYS, buf);
+        }
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+    }
+
+    // ---- normalise and store: lane holds dims dt*16 + 4g .. +3 of query li
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = l_run[qt];
+        if constexpr (LSUM) {
+            float mine = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < T::DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine = (dt * 16 + g * 4 + r == dh) ? o[dt][qt][r] : mine;
+            l = __shfl(mine, ((dh & 15) >> 2) * 16 + li, 64);
+        } else {
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
+        const float inv = 1.0f / l;
+        const int q = q0 + qt * 16 + li;
+        if (q < p.Lq) {
+            half_t* orow = p.o + ((size_t)qb * p.Lq + q) * p.ldo + head * dh;
+#pragma unroll
+            for (int dt = 0; dt < T::DT; ++dt) {
+                const int d = dt * 16 + g * 4;
+                if (d < dh) {
+                    const f32x4 v = o[dt][qt];
+                    half4_t h = {(half_t)(v[0] * inv), (half_t)(v[1] * inv), (half_t)(v[2] * inv), (half_t)(v[3] * inv)};
+                    *reinterpret_cast<half4_t*>(orow + d) = h;
+                }
+            }
+        }
+    }
+}
+
+template <int NCH, int QT, int NBUF, bool LSUM, bool SC>
+static int launch_att_dma(const AttnParams& p, hipStream_t stream) {
+    using T = AttDmaTile<NCH, LSUM>;
+    constexpr int lds = NBUF * 2 * T::TILE_BYTES + 1024;     // + slack: the last row's MFMA-width reads run past the tile
+    auto kern = attention_dma_kernel<NCH, QT, NBUF, LSUM, SC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(p.Lq, 4 * QT * 16), p.heads, p.NBq);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int DHP, int QT, int ABL = 0, bool LSUM = false, bool SC = false, int NDT = 0>
 static int launch_att(const AttnParams& p, hipStream_t stream) {
     using T = AttTile<DHP>;
@@ -336,8 +618,16 @@ static int launch_att(const AttnParams& p, hipStream_t stream) {
 }
 
 // Kernel choice by head dim: the model's head dims (40, 80, 160; 64 for completeness) get the compile-time output-tile count.
+static int g_force_qt = 0;
+void attention_force_qt(int qt) { g_force_qt = qt; }
+
 template <bool SC>
 static int dispatch_att(const AttnParams& p, bool big, bool lsum, hipStream_t stream) {
+    if (g_force_qt != 0x50) {      // LDS-DMA staging for the model's head dims (0x50: A/B switch, register-staged kernels)
+        if (p.dh == 40 && lsum) return big ? launch_att_dma<5, 2, 3, true, SC>(p, stream) : launch_att_dma<5, 1, 3, true, SC>(p, stream);
+        if (p.dh == 80) return big ? launch_att_dma<10, 2, 3, false, SC>(p, stream) : launch_att_dma<10, 1, 3, false, SC>(p, stream);
+        if (p.dh == 160) return big ? launch_att_dma<20, 2, 2, false, SC>(p, stream) : launch_att_dma<20, 1, 2, false, SC>(p, stream);
+    }
     if (p.dh <= 64) {
         if (lsum) {
             if (p.dh == 40) return big ? launch_att<64, 2, 0, true, SC, 3>(p, stream) : launch_att<64, 1, 0, true, SC, 3>(p, stream);
@@ -354,9 +644,6 @@ static int dispatch_att(const AttnParams& p, bool big, bool lsum, hipStream_t st
     if (p.dh == 160) return big ? launch_att<160, 2, 0, false, SC, 10>(p, stream) : launch_att<160, 1, 0, false, SC, 10>(p, stream);
     return big ? launch_att<160, 2, 0, false, SC>(p, stream) : launch_att<160, 1, 0, false, SC>(p, stream);
 }
-
-static int g_force_qt = 0;
-void attention_force_qt(int qt) { g_force_qt = qt; }
 
 int launch_attention(const AttnParams& p, hipStream_t stream) {
     LAVIE_CHECK(p.dh % 8 == 0 && p.dh >= 8 && p.dh <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", p.dh);

@@ -753,6 +753,8 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     WS(wide, half_t, (size_t)T * 4 * C);          // qkv [T,3C] / GEGLU output [T,4C] / q2 [T,C]
     WS(kv2, half_t, (size_t)c.B * c.ctx_len * 2 * C);
     const size_t ti = &t - transformers_.data();
+    // text K/V computed once per context by cache_context(): valid for this very ctx tensor and shape only
+    const bool kv_cached = !c.dry && kv_ctx_ != nullptr && kv_ctx_ == ctx && kv_B_ == c.B && kv_len_ == c.ctx_len && ti < kv2_cache_.size();
 
     // VSR: ResnetBlock3DCNN (3,1,1) on the block input, before the residual is taken (vsr/models/attention.py:395-400)
     if (t.tres.present) RUN(run_temporal_res(c, t.tres, x, x, C, D, nullptr, 0));
@@ -784,10 +786,12 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
             LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, T, C, 1e-5f, c.s));
             RUN(linear(c, ln, C, t.wq1, nullptr, C, C, nullptr, wide, C, T));
         }
-        RUN(linear(c, ctx, X, t.wkv1, nullptr, 2 * C, X, nullptr, kv2, 2 * C, c.B * c.ctx_len));
+        const half_t* kvc1 = kv2;
+        if (kv_cached) kvc1 = kv1_cache_[ti];
+        else RUN(linear(c, ctx, X, t.wkv1, nullptr, 2 * C, X, nullptr, kv2, 2 * C, c.B * c.ctx_len));
         if (!c.dry) {
             AttnParams a;
-            a.q = wide; a.ldq = C; a.k = kv2; a.ldk = 2 * C; a.v = kv2 + C; a.ldv = 2 * C;
+            a.q = wide; a.ldq = C; a.k = kvc1; a.ldk = 2 * C; a.v = kvc1 + C; a.ldv = 2 * C;
             a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = c.ctx_len; a.heads = heads; a.dh = dh; a.kv_batch_div = c.F; a.scale = scale;
             RUN(launch_attention(a, c.s));
         }
@@ -821,10 +825,12 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         LAUNCH(launch_layernorm(tx, t.ln2.g, t.ln2.b, ln, T, C, 1e-5f, c.s));
         RUN(linear(c, ln, C, t.wq2, nullptr, C, C, nullptr, wide, C, T));
     }
-    RUN(linear(c, ctx, X, t.wkv2, nullptr, 2 * C, X, nullptr, kv2, 2 * C, c.B * c.ctx_len));
+    const half_t* kvc2 = kv2;
+    if (kv_cached) kvc2 = kv2_cache_[ti];
+    else RUN(linear(c, ctx, X, t.wkv2, nullptr, 2 * C, X, nullptr, kv2, 2 * C, c.B * c.ctx_len));
     if (!c.dry) {
         AttnParams a;
-        a.q = wide; a.ldq = C; a.k = kv2; a.ldk = 2 * C; a.v = kv2 + C; a.ldv = 2 * C;
+        a.q = wide; a.ldq = C; a.k = kvc2; a.ldk = 2 * C; a.v = kvc2 + C; a.ldv = 2 * C;
         a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = c.ctx_len; a.heads = heads; a.dh = dh; a.kv_batch_div = c.F; a.scale = scale;
         RUN(launch_attention(a, c.s));
     }
@@ -1052,6 +1058,36 @@ int UNet::forward(const half_t* sample, const float* timesteps, const half_t* ct
     c.labels = class_labels_host;
     prep_H_ = H; prep_W_ = W;
     return run(c, sample, timesteps, ctx, out);
+}
+
+int UNet::cache_context(const half_t* ctx, int B, int ctx_len, hipStream_t stream) {
+    LAVIE_CHECK(finalized_, "cache_context: call lavie_unet_finalize first");
+    kv_ctx_ = nullptr;                              // invalid until every buffer is written
+    if (ctx == nullptr) return 0;
+    LAVIE_CHECK(B >= 1 && B <= 8 && ctx_len >= 1, "cache_context: B=%d ctx_len=%d unsupported", B, ctx_len);
+    LAVIE_CHECK(ws_.total_bytes() > 0, "cache_context: call lavie_unet_prepare first (split-K slabs come from the workspace)");
+    const size_t rows = (size_t)B * ctx_len;
+    const int X = cfg_.cross_attention_dim;
+    if (rows > kv_cache_rows_ || kv2_cache_.size() != transformers_.size()) {      // grow-only, from the weights arena
+        kv2_cache_.assign(transformers_.size(), nullptr);
+        kv1_cache_.assign(transformers_.size(), nullptr);
+        for (size_t i = 0; i < transformers_.size(); ++i) {
+            WALLOC(kv2_cache_[i], half_t, rows * 2 * transformers_[i].C);
+            if (transformers_[i].attn1_cross) WALLOC(kv1_cache_[i], half_t, rows * 2 * transformers_[i].C);
+        }
+        kv_cache_rows_ = rows;
+    }
+    ws_.release(0);
+    FwdCtx c{stream, &ws_, false, B, 1, ctx_len, nullptr};
+    for (size_t i = 0; i < transformers_.size(); ++i) {
+        const TransformerW& t = transformers_[i];
+        RUN(linear(c, ctx, X, t.wkv2, nullptr, 2 * t.C, X, nullptr, kv2_cache_[i], 2 * t.C, (int)rows));
+        if (t.attn1_cross) RUN(linear(c, ctx, X, t.wkv1, nullptr, 2 * t.C, X, nullptr, kv1_cache_[i], 2 * t.C, (int)rows));
+    }
+    kv_ctx_ = ctx;
+    kv_B_ = B;
+    kv_len_ = ctx_len;
+    return 0;
 }
 
 int UNet::resnet_forward(const char* prefix, const half_t* x1, int C1, const half_t* x2, int C2, const float* temb, half_t* y,

@@ -112,6 +112,9 @@ public:
                        int B, int F, int H, int W, hipStream_t stream);
     int transformer_forward(const char* prefix, half_t* x, const half_t* ctx, int B, int F, int H, int W, int ctx_len,
                             hipStream_t stream);
+    // Text K/V of every transformer block for one context tensor, computed once and reused by every forward that is called
+    // with the SAME ctx pointer and shape (the denoise loop passes one context for all of its steps); ctx == nullptr clears.
+    int cache_context(const half_t* ctx, int B, int ctx_len, hipStream_t stream);
     long long weight_bytes() const { return (long long)weights_.total_bytes(); }
     long long workspace_bytes() const { return (long long)ws_.total_bytes(); }
     void set_ln_fold(bool on) { ln_fold_ = on; }
@@ -162,6 +165,11 @@ private:
     };
     std::unordered_map<int, FrameTables> tables_;
     const FrameTables* cur_tables_ = nullptr;       // the entry of the running forward's F
+    // cached text K/V (cache_context): one [B * ctx_len, 2C] buffer per transformer (attn2; attn1 on VSR cross levels)
+    std::vector<half_t*> kv2_cache_, kv1_cache_;
+    size_t kv_cache_rows_ = 0;                      // rows the buffers were allocated for
+    const half_t* kv_ctx_ = nullptr;
+    int kv_B_ = 0, kv_len_ = 0;
     // spatial size of the running call (set by prepare()/forward() before run())
     int prep_H_ = 0, prep_W_ = 0;
 };

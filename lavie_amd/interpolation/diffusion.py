@@ -159,6 +159,7 @@ class SpacedDiffusion:
         else:
             inp = model_in
         unet.prepare(2 * k, x.shape[2], x.shape[3], x.shape[4], ctx.shape[1])
+        ctx = unet.cache_context(ctx)            # text keys / values once per clip, not once per block and step
         noise_dev = torch.empty_like(x)
         steps = list(range(self.num_timesteps))[::-1]
         t_dev = torch.tensor([float(self.timestep_map[i]) for i in steps], dtype=torch.float32, device=dev)
@@ -171,6 +172,7 @@ class SpacedDiffusion:
             coeffs = self.ddim_coefficients(i, eta)
             step_noise = noise_dev.normal_() if coeffs[4] != 0.0 else None
             ops.cfg_ddpm_step(eps, x, step_noise, model_in, cfg_scale, coeffs)
+        unet.cache_context(None)
         return torch.cat([x, x], dim=0)
 
 

@@ -140,6 +140,9 @@ class VideoGenPipeline:
         else:
             ops.latents_to_model_input1(x, model_in, first_scale)
         self.unet.prepare(nb, x.shape[2], x.shape[3], x.shape[4], ctx.shape[1])
+        # the context is the same tensor for every step: its keys / values are computed once (the reference recomputes
+        # them in each block of each step, attention.py:177-178)
+        ctx = self.unet.cache_context(ctx) if hasattr(self.unet, "cache_context") else ctx
 
         # per-step noise: drawn on the host only when the caller's generator lives there, then staged through
         # two pinned slots on a side stream so that neither the device nor the host waits for the other
@@ -199,6 +202,8 @@ class VideoGenPipeline:
                 step_done[slot].record(main)
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, x)
+        if hasattr(self.unet, "cache_context"):
+            self.unet.cache_context(None)
         return x
 
     @torch.no_grad()

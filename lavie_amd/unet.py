@@ -132,6 +132,7 @@ class UNet3DConditionModel(nn.Module):
         self._engine = None
         self._engine_key = None
         self._prepared = None
+        self._cached_ctx = None
 
     def _vsr_config(self, only_cross_attention, use_linear_projection, levels: int) -> dict:
         """UNetConfig fields of the VSR block variant; the base and interpolation models have none."""
@@ -176,6 +177,7 @@ class UNet3DConditionModel(nn.Module):
         self.__dict__["_engine"] = None
         self.__dict__["_engine_key"] = None
         self.__dict__["_prepared"] = None
+        self.__dict__["_cached_ctx"] = None
 
     def __del__(self):
         try:
@@ -258,6 +260,26 @@ class UNet3DConditionModel(nn.Module):
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().lavie_unet_prepare(handle, *want), "lavie_unet_prepare")
         self.__dict__["_prepared"] = want
+
+    def cache_context(self, encoder_hidden_states: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """Computes the text keys / values of every transformer block once for this context (lavie_unet_cache_context) and
+        returns the fp16 device tensor to pass as `encoder_hidden_states` while it is cached — a denoise loop calls this
+        before its first step and `cache_context(None)` after its last.  The tensor must not be modified meanwhile."""
+        handle = self._ensure_engine()
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if encoder_hidden_states is None:
+                self.__dict__["_cached_ctx"] = None
+                _lib.check(lib.lavie_unet_cache_context(handle, None, 0, 0, stream), "lavie_unet_cache_context")
+                return None
+            if self._prepared is None:
+                raise RuntimeError("cache_context: call prepare(batch, frames, height, width, ctx_len) first")
+            ctx = encoder_hidden_states.to(device=self.device, dtype=torch.float16).contiguous()
+            _lib.check(lib.lavie_unet_cache_context(handle, ctypes.c_void_p(ctx.data_ptr()), ctx.shape[0], ctx.shape[1], stream),
+                       "lavie_unet_cache_context")
+        self.__dict__["_cached_ctx"] = ctx          # keeps the tensor (and so its address) alive while cached
+        return ctx
 
     # ------------------------------------------------------------------ forward (unet.py:366-512)
     @torch.no_grad()

@@ -480,3 +480,28 @@ def test_pipeline_prompt_path_with_stock_text_encoder(small):
         ne = enc(Tok()("blurry").input_ids.cuda())[0]
     b = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, generator=torch.Generator().manual_seed(3), **kw).video
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_context_cache_is_bit_identical_and_scoped(small):
+    """lavie_unet_cache_context: text keys / values computed once per context give bit-identical outputs; another
+    context tensor (other pointer) is computed as usual; dropping the cache restores the per-call path."""
+    net, _ = small
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(2, 4, 4, 8, 8, generator=g).half().cuda()
+    c1 = torch.randn(2, 77, 128, generator=g).half().cuda()
+    c2 = torch.randn(2, 77, 128, generator=g).half().cuda()
+    ref1 = net(x, 300, encoder_hidden_states=c1).sample.clone()
+    ref2 = net(x, 300, encoder_hidden_states=c2).sample.clone()
+    assert not torch.equal(ref1, ref2)
+    cc = net.cache_context(c1)
+    assert cc.data_ptr() == c1.data_ptr()
+    assert torch.equal(net(x, 300, encoder_hidden_states=cc).sample, ref1)
+    assert torch.equal(net(x, 300, encoder_hidden_states=c2).sample, ref2)          # other tensor: not served from the cache
+    assert torch.equal(net(x, 300, encoder_hidden_states=cc).sample, ref1)
+    net.cache_context(None)
+    assert torch.equal(net(x, 300, encoder_hidden_states=c1).sample, ref1)
+    # a batch-1 call with a view of the cached tensor's first row has the same pointer but another shape: recomputed
+    net.cache_context(c1)
+    y1 = net(x[:1], 300, encoder_hidden_states=c1[:1]).sample
+    net.cache_context(None)
+    assert torch.equal(y1, net(x[:1], 300, encoder_hidden_states=c1[:1]).sample)
