@@ -330,6 +330,8 @@ def main():
             for key in ("roofline", "roofline_temporal"):
                 if key in result and key in tr:
                     result[key]["traffic"] = tr[key]
+                    result[key]["traffic_source"] = ("profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                      "of this command (tools/collect_profiles.sh), gfx950 corrections applied; not re-measured in this run")
 
     # ---- full per-class breakdown: one extra instrumented forward, outside the timed region
     if rank == 0 and use_prof:

@@ -26,14 +26,14 @@ def classes(name):
         out += ["roofline", "conv_class"]
     elif "igemm_pp_kernel<true" in name or "igemm_pp_kernelILb1" in name:
         out.append("conv_class")
-    elif "igemm_pp_kernel" in name:
+    elif "igemm_ppx_kernel" in name or "igemm_pp_kernel" in name:
         out.append("linear")
     elif "igemm_kernel" in name:
         gather = ", true," in name or "Lb1E" in name
         out.append("conv_class" if gather else "linear")
     elif "temporal_attention_kernel" in name:
         out.append("roofline_temporal")
-    elif "attention_kernel" in name:
+    elif "attention_kernel" in name or "attention_dma_kernel" in name:
         out.append("attention")
     return out
 
