@@ -426,9 +426,11 @@ static bool ppx_plan_shape(int M, int N, int nk, int epilogue) {
     // every CU gets at least one whole tile — the L0 GEMMs with K = 320 (N = 320: -14 .. -23 %, QKV -7 %, GEGLU -10 %) and
     // the L1 K = 640 linear ones (-3 .. -10 %); it loses on long K loops (the one-tile kernels' second workgroup per CU
     // hides their epilogue better) and on under-filled grids (M = 5120: 128 tiles).
+    // GEGLU: -10 % in the operator benchmark but +3 % inside the UNet (rocprofv3, profiles/r02_a_kernel_summary.md: its
+    // VALU-heavy epilogue stalls both groups once per tile): left to the one-tile kernels.
     const long tiles = (long)(M / 160) * (N / pp_bn(N));
     if (tiles < 256 || nk > 10) return false;
-    return epilogue == EPI_LINEAR || nk <= 5;
+    return epilogue == EPI_LINEAR;
 }
 static bool ppx_plan(const IgemmParams& p, int epilogue) {
     return p.splits == 1 && igemm_ppx_eligible(p, epilogue) && ppx_plan_shape(p.M, p.N, p.nk, epilogue);

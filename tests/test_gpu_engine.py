@@ -288,8 +288,9 @@ def test_fifty_ddpm_steps_reference_trajectory(full):
     tolerance".  All 50 CFG + DDPM steps of VideoGenPipeline.__call__ (latents=, prompt_embeds=, CPU generator=) at full
     width against tests/golden/ddpm_50step.pt — the reference loop (pipeline_videogen.py:662-689) around the imported
     reference UNet in fp32, noise from the same CPU generator seed.  Stated tolerance for fp16 storage over the whole
-    stochastic trajectory: rel-L2 <= 3e-2 and cosine >= 0.999 on the final latents, rel-L2 <= 2e-2 on every kept
-    intermediate (SURVEY.md §8c expected 1e-2..5e-2)."""
+    stochastic trajectory: rel-L2 <= 5e-3 and cosine >= 0.9999 on the final latents, rel-L2 <= 5e-3 on every kept
+    intermediate (measured on MI355X: 0.9e-3 .. 1.1e-3 at every kept step, cosine 0.9999994; SURVEY.md §8c had expected
+    1e-2 .. 5e-2)."""
     from lavie_amd.pipeline_videogen import VideoGenPipeline
     from lavie_amd.scheduling_ddpm import DDPMScheduler
     net, _ = full
@@ -304,8 +305,8 @@ def test_fifty_ddpm_steps_reference_trajectory(full):
     cos = torch.nn.functional.cosine_similarity(out.flatten(), fx["y"].flatten(), dim=0).item()
     print("trajectory rel-L2 per kept step:", {i: f"{e:.2e}" for i, e in errs.items()}, "final cosine", cos)
     assert torch.equal(out, seen[49])
-    assert max(errs.values()) < 2e-2, errs
-    assert rel_l2(out, fx["y"]) < 3e-2 and cos > 0.999
+    assert max(errs.values()) < 5e-3, errs
+    assert rel_l2(out, fx["y"]) < 5e-3 and cos > 0.9999
 
 
 def test_transformer3d_reference_fixture_base_width():
