@@ -319,7 +319,7 @@ def main():
                                   "flop_per_launch": conv["flops"] / conv["launches"]}
         if temp["launches"]:
             bw = temp["bytes"] / (temp["ms"] * 1e-3) / 1e9
-            result["roofline_temporal"] = {"kernel": "temporal_attention_kernel<1>", "bound": "hbm", "achieved": bw,
+            result["roofline_temporal"] = {"kernel": "temporal_stream_kernel (persistent, LDS-DMA two tiles ahead)", "bound": "hbm", "achieved": bw,
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bw / PEAK_HBM_GBS,
                                            "traffic": None, "launches": temp["launches"],
                                            "avg_launch_us": 1e3 * temp["ms"] / temp["launches"],

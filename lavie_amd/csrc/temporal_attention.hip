@@ -26,6 +26,9 @@
 
 namespace lavie {
 
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
 struct TemporalGeom {
     int PT, HG;        // pixels and heads per workgroup
     int RL;            // row length in halfs = HG * dh
@@ -255,10 +258,221 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming variant for clips of <= 16 frames (round 2).  The kernel above loads a tile, waits, computes, stores and exits:
+// nothing of one workgroup overlaps, and ~4 small workgroups per CU reached 3.4 TB/s at L0.  Here a PERSISTENT workgroup
+// (two per CU) walks (video, pixel) tiles of ONE head group of 320 channels (8 / 4 / 2 heads at dh 40 / 80 / 160: every
+// level has the same 640-byte row segments) with the q | k | v rows going HBM -> LDS by global_load_lds_dwordx4 two tiles
+// ahead (two tile buffers + a separate output buffer, counted vmcnt), the outputs leaving through an LDS row buffer as whole
+// 640-byte rows (exactly three 16-byte stores per wave and tile, inline asm, so the counted waits know their number), and
+// no ordinary global load inside the loop (rotary tables and this head group's bias rows live in registers).
+// LDS rows are padded to 672 bytes = 32 B x 21 (the conflict-free stride of the kernel above); the two pad chunks of a row
+// and the rows of frames >= F are fetched from a 16-byte zero page — the LDS-DMA source address is per lane.
+__device__ __attribute__((aligned(16))) half_t g_tmp_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __attribute__((aligned(16))) half_t g_tmp_dump_page[64 * 8];
+
+namespace tdma {
+constexpr int RL = 320;                    // channels per row segment
+constexpr int CPR = RL / 8;                // 40 real 16-byte chunks per row
+constexpr int RCH = CPR + 2;               // 42 chunks per LDS row
+constexpr int RS = RCH * 16;               // 672 B
+constexpr int ROWS = 48;                   // q | k | v x 16 frames
+constexpr int CHUNKS = ROWS * RCH;         // 2016
+constexpr int PIECES = 8;                  // per wave: 4 x 8 x 64 = 2048 >= 2016 (the last 32 lanes fetch zeros into the slack)
+constexpr int BUF_BYTES = 4 * PIECES * 1024;          // 32 KiB
+constexpr int OBUF_BYTES = 16 * RS;                   // output rows
+constexpr int LDS_BYTES = 2 * BUF_BYTES + OBUF_BYTES; // 76,288: two workgroups per CU
+}  // namespace tdma
+
+__global__ __launch_bounds__(256, 2) void temporal_stream_kernel(const TemporalParams p, const int ngroups, const int tiles_per_group) {
+    using namespace tdma;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* obuf = smem + 2 * BUF_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int F = p.F, dh = p.dh;
+    const int C = p.heads * dh;
+    const int HG = RL / dh;
+    // this workgroup: one head group, tiles (b, pixel) t0, t0 + stride, ...
+    const int hg = blockIdx.x % ngroups;
+    const int t0 = blockIdx.x / ngroups;
+    const int tstride = gridDim.x / ngroups;
+    const int col0 = hg * RL;
+    const int ntile = t0 < tiles_per_group ? (tiles_per_group - t0 + tstride - 1) / tstride : 0;
+    if (ntile == 0) return;
+
+    // ---- per-lane constants, loaded before any LDS-DMA is in flight
+    const int rpairs = p.rot_dim >> 1;
+    float rc[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = 4 * g + j;
+        const bool ok = li < F && k < rpairs;
+        rc[j] = ok ? p.rot_cos[li * rpairs + k] : 1.f;
+        rs[j] = ok ? p.rot_sin[li * rpairs + k] : 0.f;
+    }
+    // bias rows of this wave's (at most two) heads: query li, keys 4g .. 4g+3
+    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int qic = li < F ? li : F - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kj = 4 * g + r;
+            const int kc = kj < F ? kj : F - 1;
+            if (wave < HG) bias0[r] = p.bias[((size_t)(hg * HG + wave) * F + qic) * F + kc];
+            if (wave + 4 < HG) bias1[r] = p.bias[((size_t)(hg * HG + wave + 4) * F + qic) * F + kc];
+        }
+    }
+    // staging plan: piece i of this wave covers chunks (wave + 4 i) * 64 + lane of the buffer: row = chunk / 42 (array a =
+    // row / 16, frame f = row % 16), column chunk c = chunk % 42; element offset from the tile's base, or -1 = zero page
+    long goff[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int chunk = (wave + 4 * i) * 64 + lane;
+        const int row = chunk / RCH, c = chunk - row * RCH;
+        const int a = row >> 4, f = row & 15;
+        goff[i] = (chunk < CHUNKS && c < CPR && f < F) ? ((long)f * p.D * p.ld + a * C + c * 8) : -1;
+    }
+    asm volatile("" : "+v"(bias0), "+v"(bias1));          // the loads above are consumed here, not inside the loop
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(rc[j]), "+v"(rs[j]));
+
+    auto tile_base = [&](int n) -> const half_t* {          // token row of (b, frame 0, pixel) of tile n, this head group
+        const int t = t0 + n * tstride;
+        const int b = t / p.D, pix = t - b * p.D;
+        return p.qkv + ((size_t)b * F * p.D + pix) * p.ld + col0;
+    };
+    auto issue_tile = [&](int n, int buf) {
+        const half_t* base = tile_base(n);
+        char* dst = smem + buf * BUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const half_t* src = goff[i] >= 0 ? base + goff[i] : g_tmp_zero_page;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+    };
+
+    const int KS = (dh + 31) >> 5;
+    const int DT = (dh + 15) >> 4;
+    const float l2e = 1.4426950408889634f;
+
+    issue_tile(0, 0);
+    if (ntile > 1) issue_tile(1, 1);
+    for (int n = 0; n < ntile; ++n) {
+        // tile n has landed: younger than it are the pieces of tile n+1 and the three stores of tile n-1
+        {
+            const int allow = (n + 1 < ntile ? PIECES : 0) + (n > 0 ? 3 : 0);
+            if (allow == PIECES + 3) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else if (allow == PIECES) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (allow == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sQ = smem + (n & 1) * BUF_BYTES;
+        const char* sK = sQ + 16 * RS;
+        const char* sV = sQ + 32 * RS;
+
+        for (int pair = wave; pair < HG; pair += 4) {
+            const int cb = pair * dh * 2;               // byte offset of this head inside a row
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < KS; ++ks) {
+                const int d = ks * 32 + g * 8;
+                half8_t qf = {0, 0, 0, 0, 0, 0, 0, 0}, kf = qf;
+                if (d < dh) {
+                    const int off = li * RS + cb + d * 2;
+                    const half8_t qraw = *reinterpret_cast<const half8_t*>(sQ + off);
+                    const half8_t kraw = *reinterpret_cast<const half8_t*>(sK + off);
+                    if (ks == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {       // rotary on channel pairs, angles in fp32; q also takes the scale
+                            const float qe = (float)qraw[2 * j] * p.scale, qo = (float)qraw[2 * j + 1] * p.scale;
+                            const float ke = (float)kraw[2 * j], ko = (float)kraw[2 * j + 1];
+                            qf[2 * j] = (half_t)(qe * rc[j] - qo * rs[j]);
+                            qf[2 * j + 1] = (half_t)(qo * rc[j] + qe * rs[j]);
+                            kf[2 * j] = (half_t)(ke * rc[j] - ko * rs[j]);
+                            kf[2 * j + 1] = (half_t)(ko * rc[j] + ke * rs[j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) qf[j] = (half_t)((float)qraw[j] * p.scale);
+                        kf = kraw;
+                    }
+                }
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, s, 0, 0, 0);
+            }
+            // + bias, softmax over keys (rows of S^T) per query column li — operations and order of the kernel above
+            const f32x4 bv = pair < 4 ? bias0 : bias1;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = -INFINITY;
+                if (4 * g + r < F) v = (s[r] + bv[r]) * l2e;
+                s[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = exp2f(s[r] - mx); s[r] = e; sum += e; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            half4_t pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pb[r] = (half_t)(s[r] * inv);
+            // O^T[dim, query] = V^T P^T, 16 keys per MFMA -> the output row buffer
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* va = sV + (4 * g + (li >> 2)) * RS + cb + (dt * 16 + (li & 3) * 4) * 2;
+                u32x2_t raw;             // (asm for the same reason as the write below: no compiler vmcnt(0) in front of it)
+                asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"((unsigned)(size_t)LDS_PTR(va)) : "memory");
+                half4_t vf;
+                __builtin_memcpy(&vf, &raw, 8);
+                const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const int d = dt * 16 + 4 * g;
+                if (d < dh) {
+                    // (asm: hipcc orders an ordinary LDS write behind every LDS-DMA in flight with vmcnt(0))
+                    const half4_t hv = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                    u32x2_t hw;
+                    __builtin_memcpy(&hw, &hv, 8);
+                    const unsigned la = (unsigned)(size_t)LDS_PTR(obuf + li * RS + cb + d * 2);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(la), "v"(hw) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                   // every wave has left tile n's buffer; the output rows are complete
+        __builtin_amdgcn_sched_barrier(0);
+        if (n + 2 < ntile) issue_tile(n + 2, n & 1);
+        // ---- whole 640-byte output rows: wave w stores chunks 160 w .. 160 w + 159 of the 16 x 40 (three instructions)
+        {
+            const int t = t0 + n * tstride;
+            const int b = t / p.D, pix = t - b * p.D;
+            half_t* obase = p.o + ((size_t)b * F * p.D + pix) * p.ldo + col0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int id = wave * 160 + i * 64 + lane;
+                const int f = id / CPR, c = id - f * CPR;
+                const bool act = i * 64 + lane < 160 && f < F;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(obuf + (act ? f * RS + c * 16 : 0));
+                // lanes without a row write their 16 bytes to a dump page instead: the instruction always issues, so the counted
+                // waits above see exactly three stores per wave and tile
+                half_t* dst = act ? obase + (size_t)f * p.D * p.ldo + c * 8 : g_tmp_dump_page + lane * 8;
+                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+            }
+        }
+    }
+}
+
 // LDS budget per workgroup for the three staged arrays: smaller tiles = more workgroups per CU in flight
 // 0 = automatic: 33 KB for clips of <= 16 frames (measured best of 17/33/65 KB: ~4 workgroups per CU), 70 KB for the
 // 64-frame tile (61-frame interpolation clips: 4 heads per row segment instead of 2; measured 33 KB 1.39, 70 KB 1.72,
-// 135 KB 1.22 TB/s)
+// 135 KB 1.22 TB/s); any explicit budget = the tile kernel also for <= 16 frames (the A/B switch against the streaming kernel)
 static int g_temporal_budget = 0;
 void temporal_set_budget(int bytes) { g_temporal_budget = bytes; }
 
@@ -272,6 +486,24 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
     ProfileScope prof(KC_TEMPORAL, stream, 4.0 * tok * p.F * width, 4.0 * tok * width * 2.0, /*kernel_events=*/true);
     const int NT = cdiv(p.F, 16) <= 1 ? 1 : 4;
     const int FP = NT * 16;
+    // streaming kernel: clips of <= 16 frames whose head groups of 320 channels tile the width (dh 40 / 80 / 160)
+    if (NT == 1 && g_temporal_budget == 0 && 320 % p.dh == 0 && (p.heads * p.dh) % 320 == 0 && 320 / p.dh <= 8 &&
+        (double)p.F * p.D * p.ld * 2.0 < 2.0e9 && (double)p.F * p.D * p.ldo * 2.0 < 4.0e9) {
+        static bool attr = false;
+        if (!attr) {
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tdma::LDS_BYTES));
+            attr = true;
+        }
+        const int ngroups = p.heads * p.dh / 320;
+        const int tiles_per_group = p.B * p.D;
+        int per_group = 512 / ngroups;                       // two workgroups per CU
+        if (per_group > tiles_per_group) per_group = tiles_per_group;
+        const int grid = per_group * ngroups;
+        if (prof.active()) hipExtLaunchKernelGGL(temporal_stream_kernel, dim3(grid), dim3(256), tdma::LDS_BYTES, stream, prof.start(), prof.stop(), 0, p, ngroups, tiles_per_group);
+        else hipLaunchKernelGGL(temporal_stream_kernel, dim3(grid), dim3(256), tdma::LDS_BYTES, stream, p, ngroups, tiles_per_group);
+        LAVIE_HIP(hipGetLastError());
+        return 0;
+    }
     // pick (HG, PT): the largest tile whose three LDS arrays stay under the budget.  Rows are padded to 32 B x odd
     // (conflict-free ds_read_b128 over 16 frames and ds_read_b64_tr_b16 over 8 keys, see attention.hip).
     TemporalGeom gm;

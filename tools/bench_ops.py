@@ -98,18 +98,18 @@ def bench_attn():
             fn = lambda: ops.attention(q, kv[:, :c], kv[:, c:], nb=nb, lq=l, lk=lk, heads=8, kv_batch_div=div)
         us = timeit(fn)
         print(f"{nb:>3} 8 {l:>5} x{lk:>5} dh={c // 8:>3} | {us:9.1f} {4.0 * nb * l * lk * c / us / 1e6:6.0f}")
-    print("temporal: B F D C | us GB/s at LDS budget 65K / 33K / 17K")
+    print("temporal: B F D C | us GB/s streaming kernel / tile kernel at LDS budget 65K / 33K / 17K")
     for d, c in ((2560, 320), (640, 640), (160, 1280)):
         qkv = rnd(2 * 16 * d, 3 * c)
         bias = torch.randn(8, 16, 16, device=dev)
         cos, sin = ops.rotary_tables(16, 32)
         row = f"  2 16 {d:>5} {c:>5} | "
-        for budget in (66560, 33000, 17000):
+        for budget in (0, 66560, 33000, 17000):
             _lib.load().lavie_debug_temporal_budget(budget)
             us = timeit(lambda: ops.temporal_attention(qkv, 2, 16, d, 8, bias, cos, sin))
             row += f"{us:8.1f} us {4.0 * 2 * 16 * d * c * 2 / us / 1e3:6.0f} GB/s | "
         print(row)
-    _lib.load().lavie_debug_temporal_budget(33000)
+    _lib.load().lavie_debug_temporal_budget(0)
 
 
 if __name__ == "__main__":

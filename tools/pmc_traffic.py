@@ -31,7 +31,7 @@ def classes(name):
     elif "igemm_kernel" in name:
         gather = ", true," in name or "Lb1E" in name
         out.append("conv_class" if gather else "linear")
-    elif "temporal_attention_kernel" in name:
+    elif "temporal_attention_kernel" in name or "temporal_stream_kernel" in name:
         out.append("roofline_temporal")
     elif "attention_kernel" in name or "attention_dma_kernel" in name:
         out.append("attention")
