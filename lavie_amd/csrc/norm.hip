@@ -123,11 +123,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);        // nb * groups + g
     if (idx >= total) return;
     const int nb = idx / groups, g = idx - nb * groups;
+    // 16 partials per lane in flight (all loads, then the adds in the same ascending order): the one-load-per-iteration loop
+    // took 5.9 us for 1024 slabs — sixteen dependent L2 round trips — and ran 61 times per forward
     float a = 0.f, b = 0.f;
-    for (int sl = lane; sl < slabs; sl += 64) {
-        const float* src = partials + (((size_t)nb * slabs + sl) * groups + g) * 2;
-        a += src[0];
-        b += src[1];
+    constexpr int FU = 16;
+    for (int s0 = lane; s0 < slabs; s0 += 64 * FU) {
+        float2 v[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int sl = s0 + u * 64;
+            const int sc = sl < slabs ? sl : slabs - 1;
+            v[u] = *reinterpret_cast<const float2*>(partials + (((size_t)nb * slabs + sc) * groups + g) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            if (s0 + u * 64 < slabs) { a += v[u].x; b += v[u].y; }
     }
     a = wave_sum(a);
     b = wave_sum(b);
@@ -203,7 +213,10 @@ static int gn_slabs(int P, int NB, int ty, int cap_total, int* rows_per_slab) {
     const int cap = NB >= cap_total ? 1 : cap_total / NB;
     if (slabs > cap) slabs = cap;
     if (slabs < 1) slabs = 1;
-    *rows_per_slab = cdiv(P, slabs);
+    // whole unrolled iterations per row lane: a slab of 40 rows on 6 row lanes ran one 4-row iteration and then up to three
+    // rows one dependent load at a time
+    const int quantum = ty * GN_UNROLL;
+    *rows_per_slab = cdiv(cdiv(P, slabs), quantum) * quantum;
     return cdiv(P, *rows_per_slab);
 }
 
