@@ -16,6 +16,8 @@
 //    transposed reads are bank-conflict-free (stride = 32 B x odd);
 //  * online softmax in fp32 with exp2, head dims that are not MFMA multiples (40, 80) are zero
 //    padded in LDS only — HBM traffic stays at the true head width.
+#include <utility>
+
 #include "common.h"
 #include "ops.h"
 #include "profile.h"
@@ -320,6 +322,32 @@ __global__ __launch_bounds__(256, (DHP == 64 && QT == 2) ? 3 : 1) void attention
     }
 }
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// hardware-transposed 8-byte LDS read at a compile-time offset, untracked by the compiler (see attention_dma_kernel)
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_read_tr16_asm(unsigned addr) {
+    u32x2_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+// the V^T fragments of 32 keys: output tile dt = columns 16 dt .. 16 dt + 15, keys +0..15 (lo) and +16..31 (hi)
+template <int BASE, int RS, int N, int... DTs>
+__device__ __forceinline__ void att_read_v(unsigned addr, u32x2_t (&lo)[N], u32x2_t (&hi)[N], std::integer_sequence<int, DTs...>) {
+    ((lo[DTs] = lds_read_tr16_asm<BASE + DTs * 32>(addr), hi[DTs] = lds_read_tr16_asm<BASE + DTs * 32 + 16 * RS>(addr)), ...);
+}
+// one lgkmcnt(0) that the fragments pass THROUGH, so no MFMA that reads them can be scheduled above it
+template <int N, int... DTs>
+__device__ __forceinline__ void att_wait_lds(u32x2_t (&lo)[N], u32x2_t (&hi)[N], std::integer_sequence<int, DTs...>) {
+    if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2])::"memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4])::"memory");
+    else {
+        static_assert(N == 10, "head dims 40 / 80 / 160");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4])::"memory");
+        asm volatile("" : "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]), "+v"(lo[8]), "+v"(hi[8]), "+v"(lo[9]), "+v"(hi[9])::"memory");
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // LDS-DMA variant (round 2).  tools/attn_ablate.py put ~290 of the 565 us of L0 self-attention in the register-staged
 // load -> ds_write -> barrier chain: each tile's global loads had ONE tile of compute to come back in, and an L2 round
@@ -529,20 +557,22 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
         }
 
         // ---- O^T[dim, q] += V^T P^T  (V^T fragments by hardware-transposed LDS reads)
+        // The reads are inline asm with their own lgkmcnt wait: in front of a compiler-issued 8-byte LDS read hipcc drains
+        // every LDS-DMA in flight (s_waitcnt vmcnt(0)), i.e. the tiles t+1 and t+2 just asked for — once per key tile.
+        const unsigned vaddr = (unsigned)(size_t)LDS_PTR(cV + (g * 4 + (li >> 2)) * RS + (li & 3) * 8);
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2) {
+            u32x2_t lo[NDT], hi[NDT];
+            if (kt2 == 0) att_read_v<0, RS>(vaddr, lo, hi, std::make_integer_sequence<int, NDT>{});
+            else att_read_v<32 * RS, RS>(vaddr, lo, hi, std::make_integer_sequence<int, NDT>{});
+            att_wait_lds(lo, hi, std::make_integer_sequence<int, NDT>{});
 #pragma unroll
-            for (int dt = 0; dt < T::DT; ++dt) {
-                if (dt < NDT) {
-                    const char* va = cV + (kt2 * 32 + g * 4 + (li >> 2)) * RS + (dt * 16 + (li & 3) * 4) * 2;
-                    const fp16x4_raw lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va));
-                    const fp16x4_raw hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_raw*)(va + 16 * RS));
-                    half8_t vf;
-                    __builtin_memcpy(&vf, &lo, 8);
-                    __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi, 8);
+            for (int dt = 0; dt < NDT; ++dt) {
+                half8_t vf;
+                __builtin_memcpy(&vf, &lo[dt], 8);
+                __builtin_memcpy(reinterpret_cast<char*>(&vf) + 8, &hi[dt], 8);
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[kt2][qt], o[dt][qt], 0, 0, 0);
-                }
+                for (int qt = 0; qt < QT; ++qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[kt2][qt], o[dt][qt], 0, 0, 0);
             }
         }
         if (NBUF < 3) {       // two buffers (large heads): the buffer of tile t is free once every wave has finished it
