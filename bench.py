@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)      # CPU test of the rank plumbing
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = cgroup/affinity share)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline instrumentation")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the UNet forward from a hipGraph (A/B switch; implies --no-profile: events cannot be captured)")
     ap.add_argument("--ddpm-steps", type=int, default=DDPM_STEPS, help=argparse.SUPPRESS)   # debugging only
     args = ap.parse_args()
 
@@ -244,6 +246,9 @@ def main():
     for name, p in net.named_parameters():
         p.data = views[name]
     net.prepare(2, FRAMES, LAT_H, LAT_W, CTX_LEN)
+    if args.graph:
+        net.enable_graph(True)
+        args.no_profile = True
     pipe = VideoGenPipeline(unet=net, scheduler=DDPMScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear"))
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
@@ -302,6 +307,7 @@ def main():
                    "prompts_per_gpu": args.steps, "parallelism": f"prompt-dp{world}" + ("-shared-gpu-rehearsal" if share else ""),
                    "collectives": "1 weight broadcast (setup), 1 latent all_gather (timed)"},
         "outputs_finite": finite,
+        "hip_graph": bool(args.graph),
         "setup_seconds": setup_s,
         "achieved_tflops_whole_path": UNET_TFLOP * args.ddpm_steps * total_videos / elapsed / world,
         "mfma_fraction_whole_path": UNET_TFLOP * args.ddpm_steps * total_videos / elapsed / world / PEAK_MFMA_TFLOPS,

@@ -236,6 +236,12 @@ long long lavie_unet_workspace_bytes(lavie_unet_t h);
  * ctx [B, ctx_len, cross_attention_dim] fp16  ->  out [B, Cout, F, H, W] fp16. */
 int lavie_unet_forward(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx, void* out, int B,
                        int F, int H, int W, int ctx_len, void* stream);
+/* The same forward replayed from a hipGraph (the reference has no counterpart: it is the launch path of unet.py:366-512).
+ * First call with a new (pointers, shape, stream) tuple: eager.  Second: the enqueue of one forward is captured on `stream`,
+ * instantiated and launched.  Later calls with the same tuple: hipGraphLaunch.  Tensor contents may change between calls,
+ * addresses may not (a changed address simply starts over).  Runs eagerly while lavie_profile_begin is active. */
+int lavie_unet_forward_graph(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx, void* out, int B,
+                             int F, int H, int W, int ctx_len, void* stream);
 
 /* Same for a model with num_class_embeds > 0: class_labels_host[B] (host ints, the VSR noise level per video). */
 int lavie_unet_forward_labels(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx,

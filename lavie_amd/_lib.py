@@ -85,6 +85,8 @@ SIGNATURES = {
     "lavie_unet_workspace_bytes": (c_ll, [c_void_p]),
     "lavie_unet_forward": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p]),
+    "lavie_unet_forward_graph": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p]),
     "lavie_unet_forward_labels": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, C.POINTER(c_int), c_void_p, c_int, c_int,
                                            c_int, c_int, c_int, c_void_p]),
     "lavie_unet_resnet_forward": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_void_p, c_int, c_float_p, c_void_p, c_int,

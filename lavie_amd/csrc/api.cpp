@@ -313,6 +313,12 @@ int lavie_unet_forward(lavie_unet_t h, const void* sample, const float* timestep
     return h->net.forward(H(sample), timesteps, H(ctx), H(out), B, F, Hh, W, ctx_len, S(stream), nullptr);
 }
 
+int lavie_unet_forward_graph(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx, void* out, int B,
+                             int F, int Hh, int W, int ctx_len, void* stream) {
+    LAVIE_CHECK(h, "forward_graph: null handle");
+    return h->net.forward_graph(H(sample), timesteps, H(ctx), H(out), B, F, Hh, W, ctx_len, S(stream));
+}
+
 int lavie_unet_forward_labels(lavie_unet_t h, const void* sample, const float* timesteps, const void* ctx,
                               const int* class_labels_host, void* out, int B, int F, int Hh, int W, int ctx_len, void* stream) {
     LAVIE_CHECK(h && class_labels_host, "forward_labels: null handle / labels");

@@ -2,6 +2,7 @@
 // Mirrors the wiring of /root/reference/base/models/unet.py:454-506 and unet_blocks.py
 // (226-232, 320-362, 417-441, 524-574, 625-648) on channels-last activations; see DESIGN.md.
 #include "engine.h"
+#include "profile.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -74,7 +75,10 @@ void* DeviceArena::alloc(size_t bytes) {
 
 // ------------------------------------------------------------------ model structure
 UNet::UNet(const lavie_unet_config& cfg) : cfg_(cfg) { build_param_list(); }
-UNet::~UNet() {}
+UNet::~UNet() {
+    drop_graph();
+    if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
+}
 
 int UNet::validate_config() {
     const lavie_unet_config& c = cfg_;
@@ -1042,7 +1046,56 @@ int UNet::prepare(int B, int F, int H, int W, int ctx_len) {
     prep_H_ = H; prep_W_ = W;
     RUN(run(c, nullptr, nullptr, nullptr, nullptr));
     const size_t need = plan.peak() + (1 << 20);
-    if (need > ws_.total_bytes()) RUN(ws_.init_fixed(need));
+    if (need > ws_.total_bytes()) {
+        drop_graph();                               // the captured addresses die with the old workspace
+        ++graph_gen_;
+        RUN(ws_.init_fixed(need));
+    }
+    return 0;
+}
+
+void UNet::drop_graph() {
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    graph_exec_ = nullptr;
+    graph_ = nullptr;
+    graph_key_ = GraphKey();
+}
+
+int UNet::forward_graph(const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out, int B, int F, int H, int W,
+                        int ctx_len, hipStream_t stream) {
+    bool profiling = false;
+    for (int cls = 0; cls < KC_COUNT; ++cls) profiling = profiling || profile_enabled(cls);
+    GraphKey key;
+    key.sample = sample; key.t = timesteps; key.ctx = ctx; key.out = out; key.kv_ctx = kv_ctx_;
+    key.B = B; key.F = F; key.H = H; key.W = W; key.L = ctx_len; key.gen = graph_gen_; key.stream = stream;
+    if (profiling) return forward(sample, timesteps, ctx, out, B, F, H, W, ctx_len, stream, nullptr);
+    if (graph_exec_ && key == graph_key_) {
+        LAVIE_HIP(hipGraphLaunch(graph_exec_, stream));
+        return 0;
+    }
+    if (!(key == graph_seen_)) {                    // first sight of this tuple: eager (one-time setup must not be captured)
+        graph_seen_ = key;
+        return forward(sample, timesteps, ctx, out, B, F, H, W, ctx_len, stream, nullptr);
+    }
+    drop_graph();
+    // captured on a private stream (the caller's may be the legacy default stream, which cannot be captured); the graph
+    // itself is launched on the caller's stream
+    if (!cap_stream_) LAVIE_HIP(hipStreamCreateWithFlags(&cap_stream_, hipStreamNonBlocking));
+    LAVIE_HIP(hipStreamBeginCapture(cap_stream_, hipStreamCaptureModeThreadLocal));
+    const int rc = forward(sample, timesteps, ctx, out, B, F, H, W, ctx_len, cap_stream_, nullptr);
+    hipGraph_t g = nullptr;
+    const hipError_t end = hipStreamEndCapture(cap_stream_, &g);
+    if (rc != 0 || end != hipSuccess || g == nullptr) {
+        if (g) (void)hipGraphDestroy(g);
+        graph_seen_ = GraphKey();
+        if (rc != 0) return rc;
+        LAVIE_CHECK(false, "forward_graph: stream capture failed (%s)", hipGetErrorString(end));
+    }
+    graph_ = g;
+    LAVIE_HIP(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
+    graph_key_ = key;
+    LAVIE_HIP(hipGraphLaunch(graph_exec_, stream));
     return 0;
 }
 
@@ -1063,6 +1116,7 @@ int UNet::forward(const half_t* sample, const float* timesteps, const half_t* ct
 int UNet::cache_context(const half_t* ctx, int B, int ctx_len, hipStream_t stream) {
     LAVIE_CHECK(finalized_, "cache_context: call lavie_unet_finalize first");
     kv_ctx_ = nullptr;                              // invalid until every buffer is written
+    ++graph_gen_;
     if (ctx == nullptr) return 0;
     LAVIE_CHECK(B >= 1 && B <= 8 && ctx_len >= 1, "cache_context: B=%d ctx_len=%d unsupported", B, ctx_len);
     LAVIE_CHECK(ws_.total_bytes() > 0, "cache_context: call lavie_unet_prepare first (split-K slabs come from the workspace)");

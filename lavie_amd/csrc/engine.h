@@ -115,9 +115,15 @@ public:
     // Text K/V of every transformer block for one context tensor, computed once and reused by every forward that is called
     // with the SAME ctx pointer and shape (the denoise loop passes one context for all of its steps); ctx == nullptr clears.
     int cache_context(const half_t* ctx, int B, int ctx_len, hipStream_t stream);
+    // forward() replayed from a hipGraph: the first call with a new (pointers, shape) tuple runs eagerly (tables, kernel
+    // attributes), the second captures the enqueue of one forward on `stream` and launches the instantiated graph, later
+    // calls with the same tuple replay it.  Tensor CONTENTS may change between calls, addresses may not.  Falls back to the
+    // eager forward while kernel profiling is active (events cannot be recorded into a capture).
+    int forward_graph(const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out, int B, int F, int H, int W,
+                      int ctx_len, hipStream_t stream);
     long long weight_bytes() const { return (long long)weights_.total_bytes(); }
     long long workspace_bytes() const { return (long long)ws_.total_bytes(); }
-    void set_ln_fold(bool on) { ln_fold_ = on; }
+    void set_ln_fold(bool on) { ln_fold_ = on; ++graph_gen_; }
 
 private:
     void build_param_list();
@@ -138,6 +144,23 @@ private:
                    int ld_tproj, half_t* y, int H, int W);
     int run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W);
     int run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups);
+
+    struct GraphKey {
+        const void *sample = nullptr, *t = nullptr, *ctx = nullptr, *out = nullptr, *kv_ctx = nullptr;
+        int B = 0, F = 0, H = 0, W = 0, L = 0;
+        unsigned long gen = 0;          // bumped by everything that changes what a forward enqueues (workspace, caches, modes)
+        hipStream_t stream = nullptr;
+        bool operator==(const GraphKey& o) const {
+            return sample == o.sample && t == o.t && ctx == o.ctx && out == o.out && kv_ctx == o.kv_ctx && B == o.B && F == o.F &&
+                   H == o.H && W == o.W && L == o.L && gen == o.gen && stream == o.stream;
+        }
+    };
+    void drop_graph();
+    GraphKey graph_seen_, graph_key_;
+    hipGraph_t graph_ = nullptr;
+    hipGraphExec_t graph_exec_ = nullptr;
+    hipStream_t cap_stream_ = nullptr;              // capture only: nothing ever executes on it
+    unsigned long graph_gen_ = 0;
 
     lavie_unet_config cfg_;
     std::vector<ParamInfo> params_;

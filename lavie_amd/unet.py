@@ -133,6 +133,8 @@ class UNet3DConditionModel(nn.Module):
         self._engine_key = None
         self._prepared = None
         self._cached_ctx = None
+        self._graph = False
+        self._graph_io = {}
 
     def _vsr_config(self, only_cross_attention, use_linear_projection, levels: int) -> dict:
         """UNetConfig fields of the VSR block variant; the base and interpolation models have none."""
@@ -178,6 +180,7 @@ class UNet3DConditionModel(nn.Module):
         self.__dict__["_engine_key"] = None
         self.__dict__["_prepared"] = None
         self.__dict__["_cached_ctx"] = None
+        self.__dict__["_graph_io"] = {}
 
     def __del__(self):
         try:
@@ -281,6 +284,15 @@ class UNet3DConditionModel(nn.Module):
         self.__dict__["_cached_ctx"] = ctx          # keeps the tensor (and so its address) alive while cached
         return ctx
 
+    def enable_graph(self, on: bool = True) -> None:
+        """Replay the forward from a hipGraph (lavie_unet_forward_graph).  While on, the timestep and the output live in
+        per-shape buffers owned by this module, so the captured addresses repeat from call to call: the returned tensor is
+        OVERWRITTEN by the next forward of the same shape (a denoise loop consumes it at once), and `sample` /
+        `encoder_hidden_states` should be the same fp16 device tensors on every step (new addresses only cost a re-capture)."""
+        self.__dict__["_graph"] = bool(on)
+        if not on:
+            self.__dict__["_graph_io"] = {}
+
     # ------------------------------------------------------------------ forward (unet.py:366-512)
     @torch.no_grad()
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
@@ -307,13 +319,25 @@ class UNet3DConditionModel(nn.Module):
             t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
         else:
             t = torch.tensor([float(timestep)], dtype=torch.float32, device=dev)
-        t = t.expand(b).contiguous()                       # unet.py:426
-        out = torch.empty(b, self.cfg.out_channels, f, h, w, dtype=torch.float16, device=dev)
+        lib = _lib.load()
+        if self._graph:
+            io = self._graph_io.get((b, f, h, w))
+            if io is None:
+                io = (torch.empty(b, dtype=torch.float32, device=dev),
+                      torch.empty(b, self.cfg.out_channels, f, h, w, dtype=torch.float16, device=dev))
+                self._graph_io[(b, f, h, w)] = io
+            io[0].copy_(t.expand(b))                       # unet.py:426; contents change, the address does not
+            t, out = io
+            entry, what = lib.lavie_unet_forward_graph, "lavie_unet_forward_graph"
+        else:
+            t = t.expand(b).contiguous()                   # unet.py:426
+            out = torch.empty(b, self.cfg.out_channels, f, h, w, dtype=torch.float16, device=dev)
+            entry, what = lib.lavie_unet_forward, "lavie_unet_forward"
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _lib.check(_lib.load().lavie_unet_forward(handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(t.data_ptr()),
-                                                      ctypes.c_void_p(ctx.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                                      b, f, h, w, n_ctx, stream), "lavie_unet_forward")
+            _lib.check(entry(handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(t.data_ptr()),
+                             ctypes.c_void_p(ctx.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                             b, f, h, w, n_ctx, stream), what)
         if not return_dict:
             return (out,)
         return UNet3DConditionOutput(sample=out)

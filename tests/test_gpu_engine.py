@@ -506,3 +506,57 @@ def test_context_cache_is_bit_identical_and_scoped(small):
     y1 = net(x[:1], 300, encoder_hidden_states=c1[:1]).sample
     net.cache_context(None)
     assert torch.equal(y1, net(x[:1], 300, encoder_hidden_states=c1[:1]).sample)
+
+
+def test_graph_replay_is_bit_identical(small):
+    """lavie_unet_forward_graph: eager first call, capture on the second, replay afterwards — bit-identical to the eager
+    forward while the tensor contents (latents, timestep) change under fixed addresses; a new address or a changed text
+    cache starts over instead of replaying a stale graph."""
+    net, _ = small
+    g = torch.Generator().manual_seed(43)
+    xs = [torch.randn(2, 4, 4, 8, 8, generator=g).half().cuda() for _ in range(5)]
+    ctx = torch.randn(2, 77, 128, generator=g).half().cuda()
+    ts = [900, 700, 500, 300, 100]
+    ref = [net(x, t, encoder_hidden_states=ctx).sample.clone() for x, t in zip(xs, ts)]
+    net.enable_graph(True)
+    try:
+        buf = torch.empty_like(xs[0])
+        for i, (x, t) in enumerate(zip(xs, ts)):          # call 0 eager, 1 captures, 2.. replay
+            buf.copy_(x)
+            assert torch.equal(net(buf, t, encoder_hidden_states=ctx).sample, ref[i]), f"step {i}"
+        # another input address: not replayed against the old one
+        assert torch.equal(net(xs[2], ts[2], encoder_hidden_states=ctx).sample, ref[2])
+        assert torch.equal(net(xs[2], ts[2], encoder_hidden_states=ctx).sample, ref[2])
+        # the text cache changes what a forward enqueues: the graph is dropped, results stay the same
+        cc = net.cache_context(ctx)
+        for i in (0, 1, 3):
+            buf.copy_(xs[i])
+            assert torch.equal(net(buf, ts[i], encoder_hidden_states=cc).sample, ref[i])
+        net.cache_context(None)
+        buf.copy_(xs[4])
+        assert torch.equal(net(buf, ts[4], encoder_hidden_states=ctx).sample, ref[4])
+    finally:
+        net.enable_graph(False)
+
+
+def test_pipeline_with_graph_matches_eager(small):
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    net, _ = small
+    g = torch.Generator().manual_seed(44)
+    emb = torch.randn(1, 77, 128, generator=g)
+    neg = torch.randn(1, 77, 128, generator=g)
+    lat = torch.randn(1, 4, 4, 8, 8, generator=g)
+
+    def run():
+        pipe = VideoGenPipeline(unet=net)
+        return pipe(prompt_embeds=emb, negative_prompt_embeds=neg, latents=lat.clone(), num_inference_steps=6,
+                    guidance_scale=7.5, generator=torch.Generator().manual_seed(5), output_type="latent",
+                    video_length=4, height=64, width=64).video.clone()
+
+    eager = run()
+    net.enable_graph(True)
+    try:
+        graphed = run()
+    finally:
+        net.enable_graph(False)
+    assert torch.equal(eager, graphed)
