@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Streaming variant for clips of <= 16 frames (round 2).  The kernel above loads a tile, waits, computes, stores and exits:
+// Streaming variant (round 2; clips of <= 16 frames, and with NT = 4 up to 64).  The kernel above loads a tile, waits, computes, stores and exits:
 // nothing of one workgroup overlaps, and ~4 small workgroups per CU reached 3.4 TB/s at L0.  Here a PERSISTENT workgroup
 // (two per CU) walks (video, pixel) tiles of ONE head group of 320 channels (8 / 4 / 2 heads at dh 40 / 80 / 160: every
 // level has the same 640-byte row segments) with the q | k | v rows going HBM -> LDS by global_load_lds_dwordx4 two tiles
@@ -271,21 +271,40 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const TemporalP
 __device__ __attribute__((aligned(16))) half_t g_tmp_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 __device__ __attribute__((aligned(16))) half_t g_tmp_dump_page[64 * 8];
 
-namespace tdma {
-constexpr int RL = 320;                    // channels per row segment
-constexpr int CPR = RL / 8;                // 40 real 16-byte chunks per row
-constexpr int RCH = CPR + 2;               // 42 chunks per LDS row
-constexpr int RS = RCH * 16;               // 672 B
-constexpr int ROWS = 48;                   // q | k | v x 16 frames
-constexpr int CHUNKS = ROWS * RCH;         // 2016
-constexpr int PIECES = 8;                  // per wave: 4 x 8 x 64 = 2048 >= 2016 (the last 32 lanes fetch zeros into the slack)
-constexpr int BUF_BYTES = 4 * PIECES * 1024;          // 32 KiB
-constexpr int OBUF_BYTES = 16 * RS;                   // output rows
-constexpr int LDS_BYTES = 2 * BUF_BYTES + OBUF_BYTES; // 76,288: two workgroups per CU
-}  // namespace tdma
+// Geometry per frame-block count NT (16 NT frame rows per array).  NT = 1: 320-channel head groups, 32 KiB tile buffers, two
+// workgroups per CU.  NT = 4 (clips of 17..64 frames, the 61-frame interpolation model): 160-channel head groups (4 / 2 / 1
+// heads), 68 KiB tile buffers, one workgroup per CU; the work items of a tile are (head, 16-query block) pairs so the four
+// waves of a head share its query blocks (eight waves: 2 / 4 / 8 per head).
+template <int NT>
+struct Tdma {
+    static constexpr int RL = NT == 1 ? 320 : 160;          // channels per row segment
+    static constexpr int CPR = RL / 8;                      // real 16-byte chunks per row
+    static constexpr int RCH = CPR + 2;                     // chunks per LDS row: 672 / 352 B = 32 B x odd
+    static constexpr int RS = RCH * 16;
+    static constexpr int FP = 16 * NT;
+    static constexpr int ROWS = 3 * FP;                     // q | k | v
+    static constexpr int CHUNKS = ROWS * RCH;
+    static constexpr int NW = NT == 1 ? 4 : 8;              // waves per workgroup
+    static constexpr int PIECES = (CHUNKS + NW * 64 - 1) / (NW * 64);   // per wave (8 / 9); lanes past CHUNKS fetch zeros into the slack
+    static constexpr int REAL_PIECES = (CHUNKS + 63) / 64;  // 32 / 66; every wave issues PIECES (uniform counted waits): the
+    static constexpr int BUF_BYTES = REAL_PIECES * 1024;    // pieces past the buffer land in one shared 1-KiB dump slot
+    static constexpr int OBUF_BYTES = FP * RS;
+    static constexpr int DUMP = 2 * BUF_BYTES + OBUF_BYTES;
+    static constexpr int LDS_BYTES = DUMP + 1024;           // 77,312 / 158,720
+    static constexpr int STORES = (FP * CPR + NW * 64 - 1) / (NW * 64);   // 16-byte store instructions per wave and tile (3 / 3)
+    static constexpr int OCC = NT == 1 ? 2 : 1;
+    static constexpr int MAXH = NT == 1 ? 2 : 1;            // heads per wave (8 heads on 4 waves / at most 4 heads on 8 waves)
+    static constexpr int MAXQ = NT == 1 ? 1 : 2;            // 16-query blocks per wave and head
+};
+static_assert(Tdma<4>::LDS_BYTES <= 160 * 1024 && Tdma<1>::LDS_BYTES * 2 <= 160 * 1024 && Tdma<4>::CHUNKS % 64 == 0, "temporal stream tiles do not fit LDS");
 
-__global__ __launch_bounds__(256, 2) void temporal_stream_kernel(const TemporalParams p, const int ngroups, const int tiles_per_group) {
-    using namespace tdma;
+template <int N> __device__ __forceinline__ void tdma_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int NT>
+__global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_stream_kernel(const TemporalParams p, const int ngroups, const int tiles_per_group) {
+    using T = Tdma<NT>;
+    constexpr int RL = T::RL, CPR = T::CPR, RCH = T::RCH, RS = T::RS, FP = T::FP, CHUNKS = T::CHUNKS, PIECES = T::PIECES,
+                  BUF_BYTES = T::BUF_BYTES, STORES = T::STORES, NW = T::NW, MAXH = T::MAXH, MAXQ = T::MAXQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* obuf = smem + 2 * BUF_BYTES;
     const int tid = threadIdx.x;
@@ -295,6 +314,11 @@ __global__ __launch_bounds__(256, 2) void temporal_stream_kernel(const TemporalP
     const int F = p.F, dh = p.dh;
     const int C = p.heads * dh;
     const int HG = RL / dh;
+    // work split inside a tile: more heads than waves -> wave w takes heads w, w + NW, ... with every query block;
+    // fewer -> NW / HG waves share a head and split its 16-query blocks
+    const int wph = HG >= NW ? 1 : NW / HG;         // waves per head
+    const int h0 = HG >= NW ? wave : wave / wph, hstep = HG >= NW ? NW : HG;
+    const int q0 = HG >= NW ? 0 : wave % wph, qstep = wph;
     // this workgroup: one head group, tiles (b, pixel) t0, t0 + stride, ...
     const int hg = blockIdx.x % ngroups;
     const int t0 = blockIdx.x / ngroups;
@@ -305,39 +329,56 @@ __global__ __launch_bounds__(256, 2) void temporal_stream_kernel(const TemporalP
 
     // ---- per-lane constants, loaded before any LDS-DMA is in flight
     const int rpairs = p.rot_dim >> 1;
-    float rc[4], rs[4];
+    float rc[NT][4], rs[NT][4];                     // rotary angle of frame 16 t + li, channel pairs 4g .. 4g+3
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = 4 * g + j;
-        const bool ok = li < F && k < rpairs;
-        rc[j] = ok ? p.rot_cos[li * rpairs + k] : 1.f;
-        rs[j] = ok ? p.rot_sin[li * rpairs + k] : 0.f;
-    }
-    // bias rows of this wave's (at most two) heads: query li, keys 4g .. 4g+3
-    f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
-    {
-        const int qic = li < F ? li : F - 1;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kj = 4 * g + r;
-            const int kc = kj < F ? kj : F - 1;
-            if (wave < HG) bias0[r] = p.bias[((size_t)(hg * HG + wave) * F + qic) * F + kc];
-            if (wave + 4 < HG) bias1[r] = p.bias[((size_t)(hg * HG + wave + 4) * F + qic) * F + kc];
+        for (int j = 0; j < 4; ++j) {
+            const int f = t * 16 + li, k = 4 * g + j;
+            const bool ok = f < F && k < rpairs;
+            rc[t][j] = ok ? p.rot_cos[f * rpairs + k] : 1.f;
+            rs[t][j] = ok ? p.rot_sin[f * rpairs + k] : 0.f;
         }
-    }
-    // staging plan: piece i of this wave covers chunks (wave + 4 i) * 64 + lane of the buffer: row = chunk / 42 (array a =
-    // row / 16, frame f = row % 16), column chunk c = chunk % 42; element offset from the tile's base, or -1 = zero page
+    // bias rows of this wave's (head, query block) items: query 16 qt + li, keys 16 kt + 4g .. +3
+    f32x4 bias[MAXH][MAXQ][NT];
+#pragma unroll
+    for (int hi = 0; hi < MAXH; ++hi)
+#pragma unroll
+        for (int qi = 0; qi < MAXQ; ++qi) {
+            const int h = h0 + hi * hstep, qt = q0 + qi * qstep;
+            const bool have = h < HG && qt < NT;
+            const int qidx = qt * 16 + li;
+            const int qic = qidx < F ? qidx : F - 1;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kj = kt * 16 + 4 * g + r;
+                    const int kc = kj < F ? kj : F - 1;
+                    bias[hi][qi][kt][r] = have ? p.bias[((size_t)(hg * HG + h) * F + qic) * F + kc] : 0.f;
+                }
+        }
+    // staging plan: piece i of this wave covers chunks (wave + NW i) * 64 + lane of the buffer: row = chunk / RCH (array a =
+    // row / FP, frame f = row % FP), column chunk c = chunk % RCH; element offset from the tile's base, or -1 = zero page
     long goff[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-        const int chunk = (wave + 4 * i) * 64 + lane;
+        const int chunk = (wave + NW * i) * 64 + lane;
         const int row = chunk / RCH, c = chunk - row * RCH;
-        const int a = row >> 4, f = row & 15;
+        const int a = row / FP, f = row - a * FP;
         goff[i] = (chunk < CHUNKS && c < CPR && f < F) ? ((long)f * p.D * p.ld + a * C + c * 8) : -1;
     }
-    asm volatile("" : "+v"(bias0), "+v"(bias1));          // the loads above are consumed here, not inside the loop
+    // the loads above are consumed here, not inside the loop (a tracked load in flight there would cost a vmcnt(0))
 #pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(rc[j]), "+v"(rs[j]));
+    for (int hi = 0; hi < MAXH; ++hi)
+#pragma unroll
+        for (int qi = 0; qi < MAXQ; ++qi)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) asm volatile("" : "+v"(bias[hi][qi][kt]));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(rc[t][j]), "+v"(rs[t][j]));
 
     auto tile_base = [&](int n) -> const half_t* {          // token row of (b, frame 0, pixel) of tile n, this head group
         const int t = t0 + n * tstride;
@@ -349,8 +390,10 @@ __global__ __launch_bounds__(256, 2) void temporal_stream_kernel(const TemporalP
         char* dst = smem + buf * BUF_BYTES;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
+            const int x = wave + NW * i;                    // wave-uniform
             const half_t* src = goff[i] >= 0 ? base + goff[i] : g_tmp_zero_page;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+            char* d = x < T::REAL_PIECES ? dst + x * 1024 : smem + T::DUMP;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(d), 16, 0, 0);
         }
     };
 
@@ -361,86 +404,135 @@ __global__ __launch_bounds__(256, 2) void temporal_stream_kernel(const TemporalP
     issue_tile(0, 0);
     if (ntile > 1) issue_tile(1, 1);
     for (int n = 0; n < ntile; ++n) {
-        // tile n has landed: younger than it are the pieces of tile n+1 and the three stores of tile n-1
-        {
-            const int allow = (n + 1 < ntile ? PIECES : 0) + (n > 0 ? 3 : 0);
-            if (allow == PIECES + 3) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-            else if (allow == PIECES) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (allow == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // tile n has landed: younger than it are the pieces of tile n+1 and the stores of tile n-1
+        if (n + 1 < ntile) { if (n > 0) tdma_vmwait<PIECES + STORES>(); else tdma_vmwait<PIECES>(); }
+        else { if (n > 0) tdma_vmwait<STORES>(); else tdma_vmwait<0>(); }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const char* sQ = smem + (n & 1) * BUF_BYTES;
-        const char* sK = sQ + 16 * RS;
-        const char* sV = sQ + 32 * RS;
+        const char* sK = sQ + FP * RS;
+        const char* sV = sQ + 2 * FP * RS;
 
-        for (int pair = wave; pair < HG; pair += 4) {
-            const int cb = pair * dh * 2;               // byte offset of this head inside a row
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < KS; ++ks) {
-                const int d = ks * 32 + g * 8;
-                half8_t qf = {0, 0, 0, 0, 0, 0, 0, 0}, kf = qf;
-                if (d < dh) {
-                    const int off = li * RS + cb + d * 2;
-                    const half8_t qraw = *reinterpret_cast<const half8_t*>(sQ + off);
-                    const half8_t kraw = *reinterpret_cast<const half8_t*>(sK + off);
-                    if (ks == 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {       // rotary on channel pairs, angles in fp32; q also takes the scale
-                            const float qe = (float)qraw[2 * j] * p.scale, qo = (float)qraw[2 * j + 1] * p.scale;
-                            const float ke = (float)kraw[2 * j], ko = (float)kraw[2 * j + 1];
-                            qf[2 * j] = (half_t)(qe * rc[j] - qo * rs[j]);
-                            qf[2 * j + 1] = (half_t)(qo * rc[j] + qe * rs[j]);
-                            kf[2 * j] = (half_t)(ke * rc[j] - ko * rs[j]);
-                            kf[2 * j + 1] = (half_t)(ko * rc[j] + ke * rs[j]);
-                        }
-                    } else {
+        for (int hi = 0; hi < MAXH; ++hi) {
+            const int h = h0 + hi * hstep;
+            if (h >= HG || q0 >= NT) break;
+            const int cb = h * dh * 2;                  // byte offset of this head inside a row
+            // rotated K fragments of the first 32 dims: once per head, reused by every query block of this wave
+            half8_t kf0[NT];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) qf[j] = (half_t)((float)qraw[j] * p.scale);
-                        kf = kraw;
+            for (int kt = 0; kt < NT; ++kt) {
+                kf0[kt] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                if (g * 8 < dh) {
+                    const half8_t kraw = *reinterpret_cast<const half8_t*>(sK + (kt * 16 + li) * RS + cb + g * 16);
+                    if (rpairs == 0) { kf0[kt] = kraw; continue; }      // plain temporal attention (interpolation model): no rotary
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float ke = (float)kraw[2 * jj], ko = (float)kraw[2 * jj + 1];
+                        kf0[kt][2 * jj] = (half_t)(ke * rc[kt][jj] - ko * rs[kt][jj]);
+                        kf0[kt][2 * jj + 1] = (half_t)(ko * rc[kt][jj] + ke * rs[kt][jj]);
                     }
                 }
-                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, s, 0, 0, 0);
             }
-            // + bias, softmax over keys (rows of S^T) per query column li — operations and order of the kernel above
-            const f32x4 bv = pair < 4 ? bias0 : bias1;
-            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = -INFINITY;
-                if (4 * g + r < F) v = (s[r] + bv[r]) * l2e;
-                s[r] = v;
-                mx = fmaxf(mx, v);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.f;
+            for (int qi = 0; qi < MAXQ; ++qi) {
+                const int qt = q0 + qi * qstep;
+                if (qt >= NT) break;
+                float qrc[4], qrs[4];                   // the query block's rotary angles (qt is not a compile-time index)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = exp2f(s[r] - mx); s[r] = e; sum += e; }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
-            half4_t pb;
+                for (int jj = 0; jj < 4; ++jj) {
+                    qrc[jj] = rc[0][jj];
+                    qrs[jj] = rs[0][jj];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pb[r] = (half_t)(s[r] * inv);
-            // O^T[dim, query] = V^T P^T, 16 keys per MFMA -> the output row buffer
-            for (int dt = 0; dt < DT; ++dt) {
-                const char* va = sV + (4 * g + (li >> 2)) * RS + cb + (dt * 16 + (li & 3) * 4) * 2;
-                u32x2_t raw;             // (asm for the same reason as the write below: no compiler vmcnt(0) in front of it)
-                asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"((unsigned)(size_t)LDS_PTR(va)) : "memory");
-                half4_t vf;
-                __builtin_memcpy(&vf, &raw, 8);
-                const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                const int d = dt * 16 + 4 * g;
-                if (d < dh) {
-                    // (asm: hipcc orders an ordinary LDS write behind every LDS-DMA in flight with vmcnt(0))
-                    const half4_t hv = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-                    u32x2_t hw;
-                    __builtin_memcpy(&hw, &hv, 8);
-                    const unsigned la = (unsigned)(size_t)LDS_PTR(obuf + li * RS + cb + d * 2);
-                    asm volatile("ds_write_b64 %0, %1" ::"v"(la), "v"(hw) : "memory");
+                    for (int t = 1; t < NT; ++t) {
+                        qrc[jj] = qt == t ? rc[t][jj] : qrc[jj];
+                        qrs[jj] = qt == t ? rs[t][jj] : qrs[jj];
+                    }
+                }
+                f32x4 s[NT];
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int d = ks * 32 + g * 8;
+                    half8_t qf = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (d < dh) {
+                        const half8_t qraw = *reinterpret_cast<const half8_t*>(sQ + (qt * 16 + li) * RS + cb + d * 2);
+                        if (ks == 0 && rpairs != 0) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {    // rotary on channel pairs, angles in fp32; q also takes the scale
+                                const float qe = (float)qraw[2 * jj] * p.scale, qo = (float)qraw[2 * jj + 1] * p.scale;
+                                qf[2 * jj] = (half_t)(qe * qrc[jj] - qo * qrs[jj]);
+                                qf[2 * jj + 1] = (half_t)(qo * qrc[jj] + qe * qrs[jj]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) qf[jj] = (half_t)((float)qraw[jj] * p.scale);
+                        }
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) {
+                        half8_t kf = kf0[kt];
+                        if (ks > 0) {
+                            kf = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                            if (d < dh) kf = *reinterpret_cast<const half8_t*>(sK + (kt * 16 + li) * RS + cb + d * 2);
+                        }
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, s[kt], 0, 0, 0);
+                    }
+                }
+                // + bias, softmax over keys (rows of S^T) per query column li — operations and order of the tile kernel
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = -INFINITY;
+                        if (kt * 16 + 4 * g + r < F) v = (s[kt][r] + bias[hi][qi][kt][r]) * l2e;
+                        s[kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx); s[kt][r] = e; sum += e; }   // v_exp_f32: p < 2^-126 flushes to 0
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+                half4_t pb[NT];
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pb[kt][r] = (half_t)(s[kt][r] * inv);
+                // O^T[dim, query] = V^T P^T, 16 keys per MFMA -> the output row buffer.  The hardware-transposed reads and the LDS
+                // write are inline asm: in front of a compiler-issued 8-byte LDS read or any LDS write hipcc drains every
+                // LDS-DMA in flight with vmcnt(0).  The NT reads of an output tile are issued together, one wait for all.
+                for (int dt = 0; dt < DT; ++dt) {
+                    u32x2_t raw[NT];
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) {
+                        const char* va = sV + (kt * 16 + 4 * g + (li >> 2)) * RS + cb + (dt * 16 + (li & 3) * 4) * 2;
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(raw[kt]) : "v"((unsigned)(size_t)LDS_PTR(va)) : "memory");
+                    }
+                    if constexpr (NT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0])::"memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3])::"memory");
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) {
+                        half4_t vf;
+                        __builtin_memcpy(&vf, &raw[kt], 8);
+                        o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pb[kt], o, 0, 0, 0);
+                    }
+                    const int d = dt * 16 + 4 * g;
+                    if (d < dh) {
+                        const half4_t hv = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                        u32x2_t hw;
+                        __builtin_memcpy(&hw, &hv, 8);
+                        const unsigned la = (unsigned)(size_t)LDS_PTR(obuf + (qt * 16 + li) * RS + cb + d * 2);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(la), "v"(hw) : "memory");
+                    }
                 }
             }
         }
@@ -449,19 +541,19 @@ __global__ __launch_bounds__(256, 2) void temporal_stream_kernel(const TemporalP
         __builtin_amdgcn_s_barrier();                   // every wave has left tile n's buffer; the output rows are complete
         __builtin_amdgcn_sched_barrier(0);
         if (n + 2 < ntile) issue_tile(n + 2, n & 1);
-        // ---- whole 640-byte output rows: wave w stores chunks 160 w .. 160 w + 159 of the 16 x 40 (three instructions)
+        // ---- whole output rows (640 / 320 bytes): wave w stores chunks STORES * 64 * w .. of the FP x CPR
         {
             const int t = t0 + n * tstride;
             const int b = t / p.D, pix = t - b * p.D;
             half_t* obase = p.o + ((size_t)b * F * p.D + pix) * p.ldo + col0;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int id = wave * 160 + i * 64 + lane;
+            for (int i = 0; i < STORES; ++i) {
+                const int id = (wave * STORES + i) * 64 + lane;
                 const int f = id / CPR, c = id - f * CPR;
-                const bool act = i * 64 + lane < 160 && f < F;
+                const bool act = id < FP * CPR && f < F;
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(obuf + (act ? f * RS + c * 16 : 0));
                 // lanes without a row write their 16 bytes to a dump page instead: the instruction always issues, so the counted
-                // waits above see exactly three stores per wave and tile
+                // waits above see exactly STORES stores per wave and tile
                 half_t* dst = act ? obase + (size_t)f * p.D * p.ldo + c * 8 : g_tmp_dump_page + lane * 8;
                 asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
             }
@@ -486,21 +578,27 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
     ProfileScope prof(KC_TEMPORAL, stream, 4.0 * tok * p.F * width, 4.0 * tok * width * 2.0, /*kernel_events=*/true);
     const int NT = cdiv(p.F, 16) <= 1 ? 1 : 4;
     const int FP = NT * 16;
-    // streaming kernel: clips of <= 16 frames whose head groups of 320 channels tile the width (dh 40 / 80 / 160)
-    if (NT == 1 && g_temporal_budget == 0 && 320 % p.dh == 0 && (p.heads * p.dh) % 320 == 0 && 320 / p.dh <= 8 &&
+    // streaming kernel: head groups of 320 (<= 16 frames) or 160 (<= 64 frames) channels must tile the width (dh 40 / 80 / 160)
+    const int srl = NT == 1 ? 320 : 160;
+    if (g_temporal_budget == 0 && srl % p.dh == 0 && (p.heads * p.dh) % srl == 0 && srl / p.dh <= 8 &&
         (double)p.F * p.D * p.ld * 2.0 < 2.0e9 && (double)p.F * p.D * p.ldo * 2.0 < 4.0e9) {
         static bool attr = false;
         if (!attr) {
-            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tdma::LDS_BYTES));
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<1>::LDS_BYTES));
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<4>::LDS_BYTES));
             attr = true;
         }
-        const int ngroups = p.heads * p.dh / 320;
+        const int ngroups = p.heads * p.dh / srl;
         const int tiles_per_group = p.B * p.D;
-        int per_group = 512 / ngroups;                       // two workgroups per CU
+        int per_group = (NT == 1 ? 512 : 256) / ngroups;     // two / one workgroup per CU
+        if (per_group < 1) per_group = 1;
         if (per_group > tiles_per_group) per_group = tiles_per_group;
         const int grid = per_group * ngroups;
-        if (prof.active()) hipExtLaunchKernelGGL(temporal_stream_kernel, dim3(grid), dim3(256), tdma::LDS_BYTES, stream, prof.start(), prof.stop(), 0, p, ngroups, tiles_per_group);
-        else hipLaunchKernelGGL(temporal_stream_kernel, dim3(grid), dim3(256), tdma::LDS_BYTES, stream, p, ngroups, tiles_per_group);
+        const int lds = NT == 1 ? Tdma<1>::LDS_BYTES : Tdma<4>::LDS_BYTES;
+        auto kern = NT == 1 ? temporal_stream_kernel<1> : temporal_stream_kernel<4>;
+        const int threads = NT == 1 ? Tdma<1>::NW * 64 : Tdma<4>::NW * 64;
+        if (prof.active()) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, prof.start(), prof.stop(), 0, p, ngroups, tiles_per_group);
+        else hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p, ngroups, tiles_per_group);
         LAVIE_HIP(hipGetLastError());
         return 0;
     }

@@ -270,7 +270,8 @@ def test_cross_attention_text(ops, b, f, d, c):
 @pytest.mark.parametrize("b,f,d,c", [(2, 16, 24, 320), (1, 16, 10, 640), (2, 16, 5, 1280), (1, 4, 7, 320), (1, 13, 3, 256),
                                      (1, 61, 9, 320), (2, 33, 4, 640), (1, 61, 3, 1280), (1, 17, 5, 256),
                                      # several tiles per persistent workgroup of the streaming kernel, full and short clips
-                                     (2, 16, 700, 320), (1, 8, 1500, 640), (2, 16, 300, 1280), (1, 3, 2000, 320)])
+                                     (2, 16, 700, 320), (1, 8, 1500, 640), (2, 16, 300, 1280), (1, 3, 2000, 320),
+                                     (1, 61, 300, 320), (1, 40, 400, 640), (1, 64, 100, 1280)])
 def test_temporal_attention(ops, b, f, d, c):
     from oracle import unet_fp32 as O
     g = gen(f * d + c)
@@ -295,6 +296,21 @@ def test_temporal_attention(ops, b, f, d, c):
     finally:
         _lib.load().lavie_debug_temporal_budget(0)
     assert rel_l2(got, tiled.float().cpu()) < 1e-4 and (got.float() - tiled.float()).abs().max() <= 2e-3 * tiled.float().abs().max()
+
+
+@pytest.mark.parametrize("b,f,d,c", [(1, 16, 300, 320), (1, 61, 200, 320), (1, 33, 150, 1280), (1, 5, 7, 256)])
+def test_temporal_attention_plain(ops, b, f, d, c):
+    """The interpolation model's temporal attention: no rotary embedding, no relative-position bias
+    (interpolation/models/attention.py:566-606 with use_relative_position=False) = softmax(q k^T / sqrt(dh)) v per pixel."""
+    g = gen(f * d + c + 1)
+    heads, dh = 8, c // 8
+    qkv = q16(torch.randn(b * f * d, 3 * c, generator=g))
+    seq = qkv.reshape(b, f, d, 3, heads, dh).permute(3, 0, 2, 4, 1, 5).reshape(3, b * d, heads, f, dh)
+    att = torch.softmax(seq[0] @ seq[1].transpose(-1, -2) * dh ** -0.5, dim=-1) @ seq[2]
+    ref = att.reshape(b, d, heads, f, dh).permute(0, 3, 1, 2, 4).reshape(b * f * d, c)
+    bias = torch.zeros(heads, f, f)
+    got = ops.temporal_attention(h16(qkv), b, f, d, heads, f32(bias), None, None, rot_dim=0)
+    assert rel_l2(got, ref) < TOL_OP
 
 
 def test_relpos_bias_matches_oracle_tables(ops):
