@@ -352,7 +352,7 @@ def main():
         rows = profile_end(lib)
         fwd_ms = 1e3 * (time.perf_counter() - t1)
         for key, row, kernels in (("roofline_conv_class", rows[0], "igemm_patch_kernel, igemm_pp_kernel<true>, igemm_kernel<..., true, ...>, splitk_reduce_kernel"),
-                                  ("roofline_linear_class", rows[1], "igemm_pp_kernel<false>, igemm_kernel<..., false, ...>, splitk_reduce_kernel")):
+                                  ("roofline_linear_class", rows[1], "igemm_ppx_kernel, igemm_pp_kernel<false>, igemm_kernel<..., false, ...>, splitk_reduce_kernel")):
             if row["launches"] and row["ms"] > 0:     # whole classes, from the instrumented forward AFTER the timed region
                 a = row["flops"] / (row["ms"] * 1e-3) / 1e12
                 result[key] = {"kernels": kernels, "source": "one instrumented UNet forward after the timed region", "bound": "mfma",
