@@ -331,6 +331,12 @@ __device__ __forceinline__ u32x2_t lds_read_tr16_asm(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
     return r;
 }
+template <int OFF>
+__device__ __forceinline__ u32x2_t lds_read_b64_asm(unsigned addr) {
+    u32x2_t r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
 // the V^T fragments of 32 keys: output tile dt = columns 16 dt .. 16 dt + 15, keys +0..15 (lo) and +16..31 (hi)
 template <int BASE, int RS, int N, int... DTs>
 __device__ __forceinline__ void att_read_v(unsigned addr, u32x2_t (&lo)[N], u32x2_t (&hi)[N], std::integer_sequence<int, DTs...>) {
@@ -376,6 +382,10 @@ struct AttDmaTile {
     static constexpr int TILE_BYTES = ATT_KEYS * RS;                     // one of K / V = R KiB
     static constexpr int PIECES = R / 2;                                 // 1-KiB pieces per wave and tile (K and V together: 2 R)
     static constexpr int KS = DHP / 32, DT = DHP / 16, NDT = (NCH * 8 + 15) / 16;
+    // Q K^T contraction: KS32 k-steps of 32 dims (mfma 16x16x32) and, when at most 16 dims are left (head dim 40: dims 32..39),
+    // ONE 16-deep step (mfma 16x16x16, half the matrix-pipe time of a second 32-deep step that would be 75 % padding)
+    static constexpr int TAIL16 = (NCH * 8) % 32 != 0 && (NCH * 8) % 32 <= 16 ? 1 : 0;
+    static constexpr int KS32 = TAIL16 ? NCH * 8 / 32 : KS;
 };
 
 template <int NCH, int QT, int NBUF, bool LSUM, bool SC>
@@ -399,18 +409,22 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
     const int q0 = blockIdx.x * (4 * QT * 16) + wave * (QT * 16);
 
     // ---- Q fragments (B operand): lane holds Q[q = li][dims 32 ks + 8 g .. +7]
-    half8_t qf[QT][T::KS];
+    half8_t qf[QT][T::KS32];
+    half4_t qtail[QT];               // TAIL16: Q[q = li][dims 32 KS32 + 4 g .. +3] (zero past the head dim)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         int q = q0 + qt * 16 + li;
         q = q < p.Lq ? q : p.Lq - 1;
         const half_t* qrow = p.q + ((size_t)qb * p.Lq + q) * p.ldq + head * dh;
 #pragma unroll
-        for (int ks = 0; ks < T::KS; ++ks) {
+        for (int ks = 0; ks < T::KS32; ++ks) {
             const int d = ks * 32 + g * 8;
             if (d < dh) qf[qt][ks] = *reinterpret_cast<const half8_t*>(qrow + d);
             else qf[qt][ks] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
         }
+        const int dtl = T::KS32 * 32 + g * 4;
+        qtail[qt] = (half4_t){0, 0, 0, 0};
+        if (T::TAIL16 && dtl < dh) qtail[qt] = *reinterpret_cast<const half4_t*>(qrow + dtl);
     }
 
     const half_t* kbase = p.k + (SC ? (size_t)0 : (size_t)kvb * p.Lk * p.ldk) + head * dh;
@@ -465,7 +479,9 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int ks = 0; ks < T::KS; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
+        for (int ks = 0; ks < T::KS32; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) asm volatile("" : "+v"(qtail[qt]));
     issue_tile(0, 0);
     if (ntile > 1) issue_tile(ATT_KEYS, 1 % NBUF);
 
@@ -489,12 +505,30 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) s[kt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < T::KS; ++ks) {
+        for (int ks = 0; ks < T::KS32; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const half8_t kf = *reinterpret_cast<const half8_t*>(cK + (kt * 16 + li) * RS + (ks * 4 + g) * 16);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[kt][qt], 0, 0, 0);
+            }
+        }
+        if constexpr (T::TAIL16 != 0) {
+            // K[key][dims 32 KS32 + 4 g .. +3]: 8-byte reads, inline asm (a compiler-issued ds_read_b64 would drain the DMA stream)
+            const unsigned kaddr = (unsigned)(size_t)LDS_PTR(cK + li * RS + T::KS32 * 64 + g * 8);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {      // two key blocks at a time: four fragments in flight cost 8 VGPRs = spills
+                u32x2_t ka = half == 0 ? lds_read_b64_asm<0>(kaddr) : lds_read_b64_asm<32 * RS>(kaddr);
+                u32x2_t kb = half == 0 ? lds_read_b64_asm<16 * RS>(kaddr) : lds_read_b64_asm<48 * RS>(kaddr);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ka), "+v"(kb)::"memory");
+                half4_t kfa, kfb;
+                __builtin_memcpy(&kfa, &ka, 8);
+                __builtin_memcpy(&kfb, &kb, 8);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    s[2 * half][qt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kfa, qtail[qt], s[2 * half][qt], 0, 0, 0);
+                    s[2 * half + 1][qt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kfb, qtail[qt], s[2 * half + 1][qt], 0, 0, 0);
+                }
             }
         }
 
