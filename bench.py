@@ -148,7 +148,11 @@ def spawn_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out0, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    for line in out0.splitlines():                 # the contract is ONE JSON line on stdout: library chatter (gloo prints
+        if line.lstrip().startswith("{"):          # its rendezvous banner to stdout) goes to stderr
+            sys.stdout.write(line + "\n")
+        elif line.strip():
+            sys.stderr.write(line + "\n")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
