@@ -65,8 +65,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_kernel(const IgemmParam
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int m0 = (bid / n_tiles) * T::BM;
-    const int n0 = (bid % n_tiles) * T::BN;
+    int tile_m, tile_n;
+    igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, &tile_m, &tile_n);
+    const int m0 = tile_m * T::BM;
+    const int n0 = tile_n * T::BN;
 
     // ---- staging addresses ----
     const int lr = lane >> 3;                       // row of this lane inside an 8-row piece

@@ -6,6 +6,29 @@
 
 namespace lavie {
 
+// Logical tile id (XCD-contiguous, in dispatch order inside an XCD) -> (M tile, N tile).
+// N-fastest order makes a round of concurrently running tiles of one XCD (32 CUs) = ONE M tile x 32 N tiles when the GEMM is
+// wide: every M tile then streams the whole weight matrix through the fabric again (PMC, round 2: the L2-level GEGLU GEMM
+// read 869 MB for 39 MB of operands, 5.6 TB/s of fabric traffic under a 154 us kernel).  Wide GEMMs (more than 4 N tiles)
+// therefore run in blocks of 32 ids = mr x nr tiles (8 x 4 or 16 x 2): a round shares nr weight slices and mr activation
+// tiles.  Narrow ones keep N-fastest order (a round = 32 / n_tiles M tiles x all N tiles, which shares the A tiles).
+#ifndef LAVIE_TILE_BLOCKS
+#define LAVIE_TILE_BLOCKS 1
+#endif
+__device__ __forceinline__ void igemm_tile_of(int id, int m_tiles, int n_tiles, int* mt, int* nt) {
+    const int nr = n_tiles % 4 == 0 ? 4 : 2, mr = 32 / nr;
+    if (!LAVIE_TILE_BLOCKS || n_tiles <= 4 || (n_tiles & 1) || m_tiles % mr != 0) {
+        *mt = id / n_tiles;
+        *nt = id - *mt * n_tiles;
+        return;
+    }
+    const int blk = id >> 5, w = id & 31;
+    const int nbn = n_tiles / nr;
+    const int bm = blk / nbn, bn = blk - bm * nbn;
+    *mt = bm * mr + (w & (mr - 1));
+    *nt = bn * nr + w / mr;
+}
+
 // Lane layout on entry (v_mfma_f32_16x16x32_f16 with the weight tile as the A operand): acc[nt][mt][r] is output
 // channel ncol + nt*16 + r of token mrow + mt*16.  `nwave0` = first channel of this wave's tile (GEGLU column maths).
 template <int MT, int NT, int EPI>

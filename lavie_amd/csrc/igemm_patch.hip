@@ -68,8 +68,10 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
     }
-    const int m0 = (bid / n_tiles) * BM;
-    const int n0 = (bid % n_tiles) * BN;
+    int tile_m, tile_n;
+    igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, &tile_m, &tile_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
     const int split = blockIdx.y;
     const int nslab = p.nk / 9;
     const int slab_begin = (int)((long)nslab * split / p.splits);

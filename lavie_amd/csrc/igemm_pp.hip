@@ -73,8 +73,10 @@ __global__ __launch_bounds__(pp::THREADS, 2) void igemm_pp_kernel(const IgemmPar
         const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
     }
-    const int m0 = (bid / n_tiles) * BM;
-    const int n0 = (bid % n_tiles) * BN;
+    int tile_m, tile_n;
+    igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, &tile_m, &tile_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
     const int split = blockIdx.y;
     const int t_begin = (int)((long)p.nk * split / p.splits);
     const int t_end = (int)((long)p.nk * (split + 1) / p.splits);
