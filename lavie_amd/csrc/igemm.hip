@@ -27,6 +27,10 @@
 #include "igemm_epilogue.h"
 #include "profile.h"
 
+#ifndef LAVIE_SPLITK_MFAST
+#define LAVIE_SPLITK_MFAST 1      // A/B switch of the split-K tile order below
+#endif
+
 namespace lavie {
 
 template <int WM, int WN, int MT, int NT, int NSTAGE>
@@ -59,14 +63,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_kernel(const IgemmParam
 
     // ---- XCD-aware tile order (bijective for any grid size) ----
     const int n_tiles = p.N / T::BN;
-    int bid = blockIdx.x;
-    {
+    int tile_m, tile_n, split = 0;
+    if (gridDim.y == 1 || !LAVIE_SPLITK_MFAST) {
+        int bid = blockIdx.x;
         const int nwg = gridDim.x;
+        split = blockIdx.y;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, &tile_m, &tile_n);
+    } else {
+        // split-K = the weight-bound convolutions of the deep levels (M 1280, K 11520 .. 23040: 30 - 59 MB of weights for
+        // 3 MB of activations).  N-fastest order spread the M tiles that share a weight slice over all eight XCDs and every XCD
+        // pulled most of W through the fabric (PMC: 244 / 352 MB read per launch, ~5 TB/s under the kernel).  Here the whole
+        // (x, y) grid is linearised as the hardware dispatches it, made XCD-contiguous, and walked M tile fastest, then N
+        // tile, then K split: the workgroups that share a weight slice are neighbours inside one XCD's L2.
+        const int nwg = gridDim.x * gridDim.y;
+        int lin = blockIdx.x + blockIdx.y * gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        const int m_tiles = (int)gridDim.x / n_tiles;
+        tile_m = lin % m_tiles;
+        const int rest = lin / m_tiles;
+        tile_n = rest % n_tiles;
+        split = rest / n_tiles;
     }
-    int tile_m, tile_n;
-    igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, &tile_m, &tile_n);
     const int m0 = tile_m * T::BM;
     const int n0 = tile_n * T::BN;
 
@@ -122,7 +142,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_kernel(const IgemmParam
     }
 
     // split-K: this workgroup owns K-tiles [t_begin, t_end) of the flattened K loop
-    const int split = blockIdx.y;
     const int t_begin = (int)((long)p.nk * split / p.splits);
     const int t_end = (int)((long)p.nk * (split + 1) / p.splits);
 
