@@ -70,6 +70,7 @@ int launch_igemm_ppx(const IgemmParams& p, int epilogue, hipStream_t stream);
 int igemm_ppx_read_stamps(unsigned long long* out);   // diagnostic stamp build (mode 0x37): [8 waves][32] cycle sums of workgroup 0
 // 320x160 halo-patch 3x3 conv kernel (igemm_patch.hip): stride 1, 9-tap segments only; the caller runs the split-K reduce.
 bool igemm_patch_eligible(const IgemmParams& p);
+int igemm_patch_bn(int N);                        // 160 / 128 / 0: column-tile width of the halo-patch kernel for N channels
 int launch_igemm_patch(const IgemmParams& p, hipStream_t stream);
 int igemm_patch_read_stamps(unsigned long long* out);   // diagnostic stamp build: [8 waves][16] cycle sums of workgroup 0
 // Split-K factor the launcher would like for this problem (1 = none); slab size = splits * M * N floats.

@@ -395,9 +395,10 @@ static int pp_plan(int M, int N, int nk, int epilogue) {
 // (tools/check_patch.py); same grid rule with its own tile: one workgroup per CU, last round at least 85 % full,
 // split-K (over whole slabs) only with at least 45 K-tiles per split.
 static bool patch_fits(int M, int N, int nk, int s) {
-    if (M % 320 != 0 || N % 160 != 0 || nk % 9 != 0 || s < 1 || s > nk / 9) return false;
+    const int bn = igemm_patch_bn(N);
+    if (M % 320 != 0 || bn == 0 || nk % 9 != 0 || s < 1 || s > nk / 9) return false;
     if (s > 1 && nk / s < 45) return false;
-    const double r = (double)(M / 320) * (N / 160) * s / 256.0;
+    const double r = (double)(M / 320) * (N / bn) * s / 256.0;
     return r / ceil(r) >= 0.85;
 }
 static bool patch_allowed() { const int lo = g_force_tile & 0xF; return lo == 0 || lo == 5 || lo == 8; }

@@ -31,9 +31,11 @@ __device__ __forceinline__ void igemm_tile_of(int id, int m_tiles, int n_tiles, 
 
 // Lane layout on entry (v_mfma_f32_16x16x32_f16 with the weight tile as the A operand): acc[nt][mt][r] is output
 // channel ncol + nt*16 + r of token mrow + mt*16.  `nwave0` = first channel of this wave's tile (GEGLU column maths).
-template <int MT, int NT, int EPI>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int mrow, int ncol, int nwave0,
-                                               int lane, int split) {
+// `rowof(mt)` = output row of this lane in 16-row slice mt (contiguous tiles: mrow + 16 mt; the 2-D tiles of the halo-patch
+// conv kernel map slices to image rows themselves).
+template <int MT, int NT, int EPI, class RowFn>
+__device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 (&acc)[NT][MT], RowFn rowof, int ncol, int nwave0,
+                                                    int lane, int split) {
     // ---- folded LayerNorm of the A rows: acc <- rstd_m * (acc - mean_m * s_n); the folded bias comes in as p.bias
     if (p.ln_stats) {
         f32x4 sv[NT];
@@ -42,7 +44,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         float mean[MT], rstd[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = mrow + mt * 16;
+            const int m = rowof(mt);
             const int mc = m < p.M ? m : p.M - 1;
             mean[mt] = p.ln_stats[(size_t)mc * 2];
             rstd[mt] = p.ln_stats[(size_t)mc * 2 + 1];
@@ -67,7 +69,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             // the whole wave tile's loads up front buys nothing and costs ~90 VGPRs)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m = mrow + mt * 16;
+                const int m = rowof(mt);
                 const int mc = m < p.M ? m : p.M - 1;              // clamp: loads stay in bounds, stores are predicated
                 float rs_sum = 0.f, rs_sq = 0.f;
                 f32x4 b2v[NT];
@@ -110,7 +112,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             static_assert(EPI != EPI_GEGLU || NT % 2 == 0, "GEGLU needs value/gate tile pairs");
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m = mrow + mt * 16;
+                const int m = rowof(mt);
 #pragma unroll
                 for (int nt = 0; nt < NT; nt += 2) {
                     const f32x4 h = acc[nt][mt] + bv[nt], g = acc[nt + 1][mt] + bv[nt + 1];
@@ -127,7 +129,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         float* slab = p.slab + (size_t)split * p.M * p.N;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = mrow + mt * 16;
+            const int m = rowof(mt);
             if (m < p.M) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -149,6 +151,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         case 6: epilogue(T0{}, T1{}, T1{}); break;
         default: epilogue(T1{}, T1{}, T1{}); break;
     }
+}
+
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int mrow, int ncol, int nwave0,
+                                               int lane, int split) {
+    igemm_epilogue_rows<MT, NT, EPI>(p, acc, [mrow](int mt) { return mrow + mt * 16; }, ncol, nwave0, lane, split);
 }
 
 }  // namespace lavie

@@ -30,17 +30,21 @@
 namespace lavie {
 
 namespace pt {
-constexpr int MT = 5, NT = 5;
-constexpr int BM = 320, BN = 160, THREADS = 512;
+constexpr int MT = 5;
+constexpr int BM = 320, THREADS = 512;
 constexpr int PATCH_ROWS = 448, PATCH_PIECES = PATCH_ROWS / 8;     // 56
 constexpr int PATCH_STRIDE = (PATCH_ROWS + 1) * 128;                // 57,472: 448 patch rows + one row of zeros ("row 448")
-constexpr int W_BYTES = BN * 128;                                   // 20,480
+constexpr int W_BYTES_MAX = 160 * 128;                              // 20,480 (the 128-wide tile uses 16,384 of it)
 constexpr int W_BASE = 2 * PATCH_STRIDE;
-constexpr int PTAB = W_BASE + 2 * W_BYTES;                          // int[PATCH_ROWS]: source pixel of a patch row or -1
+constexpr int PTAB = W_BASE + 2 * W_BYTES_MAX;                      // int[PATCH_ROWS]: source pixel of a patch row or -1
 constexpr int SEGTAB = PTAB + PATCH_ROWS * 4;
 constexpr int TAPTAB = SEGTAB + IGEMM_MAX_SEG * 6 * 4;              // u16[9][320]: (u << 3) | (u & 7), u = patch row read by
 constexpr int LDS_BYTES = TAPTAB + 9 * BM * 2;                      //   tile row r at that tap (448 = the zero row)
 static_assert(LDS_BYTES <= 160 * 1024, "does not fit LDS");
+// 2-D tiles (image rows wider than a tile: the VSR stage's 512 / 256 / 128-pixel rows): 10 image rows x 32 columns = 320
+// pixels, patch = 12 x 34 = 408 rows with the halo columns staged explicitly
+constexpr int T2_W = 32, T2_H = 10, T2_PW = T2_W + 2, T2_ROWS = (T2_H + 2) * T2_PW;
+static_assert(T2_W * T2_H == BM && T2_ROWS <= PATCH_ROWS && T2_W % 16 == 0, "2-D tile geometry");
 }  // namespace pt
 
 // STAMP (diagnostic build, forced with lavie_debug_force_tile(0x75)): s_memtime at every phase boundary; the per-wave sums
@@ -49,9 +53,11 @@ static_assert(LDS_BYTES <= 160 * 1024, "does not fit LDS");
 // arithmetic, 9 LDS-DMA wait, 10 barrier; [11] = K-tiles.  Read the SHARES, never the run time of this build (guide section 7, In-kernel stamps).
 __device__ unsigned long long g_patch_stamps[8 * 16];
 
-template <int EPI, int STAMP = 0>
+// NT = 16-column blocks per wave: 5 -> 320x160 tile (every channel count of the base model), 4 -> 320x128 (the VSR widths)
+template <int EPI, int STAMP = 0, int NT = 5, bool T2 = false>
 __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const IgemmParams p) {
     using namespace pt;
+    constexpr int BN = 2 * NT * 16, W_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = threadIdx.x;
@@ -82,22 +88,37 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     const int kofs = ((lane & 7) ^ lr) * 8;         // source K offset (halfs) after the slot swizzle
     auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
-    // ---- tile geometry: 320 pixels = `rows_seg` image rows of each of `nf` frame segments
+    // ---- tile geometry: 320 pixels = `rows_seg` image rows of each of `nf` frame segments, or (t2) 10 rows x 32 columns
     const int Wd = p.Wo, Hd = p.Ho, HW = Hd * Wd;
+    constexpr bool t2 = T2;                         // the launcher instantiates T2 exactly when BM % Wd != 0
     const int seg_px = HW >= BM ? BM : HW;          // pixels of one frame segment inside the tile
     const int rows_seg = seg_px / Wd;
     const int PF = (rows_seg + 2) * Wd;             // patch rows of one segment (with the two halo image rows)
     const int frame0 = m0 / HW;
     const int y_first = HW >= BM ? (m0 - frame0 * HW) / Wd : 0;
+    int ty0 = 0, tx0 = 0;                           // t2: image position of the tile's first pixel
+    if (t2) {
+        const int tpr = Wd / T2_W;
+        const int tin = tile_m - frame0 * (HW / BM);
+        ty0 = (tin / tpr) * T2_H;
+        tx0 = (tin - (tin / tpr) * tpr) * T2_W;
+    }
 
     int* ptab = reinterpret_cast<int*>(smem + PTAB);
     int* segtab = reinterpret_cast<int*>(smem + SEGTAB);
     for (int j = tid; j < PATCH_ROWS; j += THREADS) {
-        const int f = j / PF, jj = j - f * PF;
-        const int jr = jj / Wd, x = jj - jr * Wd;
-        const int yy = y_first - 1 + jr;
-        const bool ok = f * seg_px < BM && (unsigned)yy < (unsigned)Hd;
-        ptab[j] = ok ? ((frame0 + f) * Hd + yy) * Wd + x : -1;
+        if (t2) {
+            const int py = j / T2_PW, px = j - py * T2_PW;
+            const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
+            const bool ok = j < T2_ROWS && (unsigned)yy < (unsigned)Hd && (unsigned)xx < (unsigned)Wd;
+            ptab[j] = ok ? (frame0 * Hd + yy) * Wd + xx : -1;
+        } else {
+            const int f = j / PF, jj = j - f * PF;
+            const int jr = jj / Wd, x = jj - jr * Wd;
+            const int yy = y_first - 1 + jr;
+            const bool ok = f * seg_px < BM && (unsigned)yy < (unsigned)Hd;
+            ptab[j] = ok ? ((frame0 + f) * Hd + yy) * Wd + x : -1;
+        }
     }
     if (tid < 64) reinterpret_cast<float*>(smem + (tid >> 5) * PATCH_STRIDE + PATCH_ROWS * 128)[tid & 31] = 0.f;
     {   // tap table: which patch row tile row r reads at tap (dy, dx); column wrap-around -> the zero row
@@ -105,10 +126,15 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         for (int idx = tid; idx < 9 * BM; idx += THREADS) {
             const int tap = idx / BM, r = idx - tap * BM;
             const int dy = tap / 3, dx = tap - dy * 3;
-            const int f = r / seg_px, rr = r - f * seg_px;
-            const int x = rr % Wd;
-            const bool bad = (dx == 0 && x == 0) || (dx == 2 && x == Wd - 1);
-            const int u = bad ? PATCH_ROWS : f * PF + Wd + rr + (dy - 1) * Wd + (dx - 1);
+            int u;
+            if (t2) {                                       // halo columns are part of the patch: no wrap-around case
+                u = (r / T2_W + dy) * T2_PW + (r % T2_W) + dx;
+            } else {
+                const int f = r / seg_px, rr = r - f * seg_px;
+                const int x = rr % Wd;
+                const bool bad = (dx == 0 && x == 0) || (dx == 2 && x == Wd - 1);
+                u = bad ? PATCH_ROWS : f * PF + Wd + rr + (dy - 1) * Wd + (dx - 1);
+            }
             taptab[idx] = (unsigned short)((u << 3) | (u & 7));
         }
     }
@@ -168,15 +194,15 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     // ---- weight pieces of this wave: rows 80 grp + (q + 4 j) * 8, j = 0..2 (j = 2 only for q < 2: 10 pieces per half)
     const half_t* wptr[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) wptr[j] = p.W + (size_t)(n0 + grp * 80 + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
-    const bool w3 = q < 2;
+    for (int j = 0; j < 3; ++j) wptr[j] = p.W + (size_t)(n0 + grp * (NT * 16) + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
+    const bool w3 = NT == 5 && q < 2;               // 80 rows per group = 10 pieces; 64 rows = 8 pieces: two per wave
     auto issue_w01 = [&](int t, int wst) {
-        char* base = smem + W_BASE + wst * W_BYTES + grp * (80 * 128);
+        char* base = smem + W_BASE + wst * W_BYTES + grp * (NT * 16 * 128);
         __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[0] + t * IGEMM_BK), LDS_PTR(base + q * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[1] + t * IGEMM_BK), LDS_PTR(base + (q + 4) * 1024), 16, 0, 0);
     };
     auto issue_w2 = [&](int t, int wst) {
-        char* base = smem + W_BASE + wst * W_BYTES + grp * (80 * 128);
+        char* base = smem + W_BASE + wst * W_BYTES + grp * (NT * 16 * 128);
         if (w3) __builtin_amdgcn_global_load_lds(GLB_PTR(wptr[2] + t * IGEMM_BK), LDS_PTR(base + (q + 8) * 1024), 16, 0, 0);
     };
 
@@ -319,8 +345,14 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
             g_patch_stamps[wave * 16 + 11] = (unsigned long long)(t_end - t_begin);
         }
     }
-    igemm_epilogue<MT, NT, EPI>(p, acc, m0 + wm * (MT * 16) + (lane & 15), n0 + wn * (NT * 16) + (lane >> 4) * 4,
-                                n0 + wn * (NT * 16), lane, split);
+    if constexpr (t2) {       // slice mt of wave row wm = 16 pixels of image row ty0 + (5 wm + mt) / 2, columns tx0 + 16 ((5 wm + mt) & 1) ..
+        const int rbase = (frame0 * Hd + ty0) * Wd + tx0 + (lane & 15);
+        igemm_epilogue_rows<MT, NT, EPI>(p, acc, [=](int mt) { const int r16 = 5 * wm + mt; return rbase + (r16 >> 1) * Wd + (r16 & 1) * 16; },
+                                         n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);
+    } else {
+        igemm_epilogue<MT, NT, EPI>(p, acc, m0 + wm * (MT * 16) + (lane & 15), n0 + wn * (NT * 16) + (lane >> 4) * 4,
+                                    n0 + wn * (NT * 16), lane, split);
+    }
 }
 
 static int g_patch_stamp = 0;      // 0 off, 1 stamps, 2 stamps without the weight LDS-DMA (wrong results), 3 stamps without the patch LDS-DMA
@@ -330,35 +362,42 @@ int igemm_patch_read_stamps(unsigned long long* out) {
     return 0;
 }
 
+// Column-tile width the halo-patch kernel uses for N output channels: 160 (base widths), 128 (VSR widths), 0 = none.
+int igemm_patch_bn(int N) { return N % 160 == 0 ? 160 : N % 128 == 0 ? 128 : 0; }
+
 // Whether the halo-patch kernel can run this conv (geometry only; the caller decides on grid fill and split-K).
 bool igemm_patch_eligible(const IgemmParams& p) {
-    if (p.stride != 1 || p.ups != 0 || p.N % pt::BN != 0 || p.M % pt::BM != 0 || p.nk % 9 != 0) return false;
+    if (p.stride != 1 || p.ups != 0 || igemm_patch_bn(p.N) == 0 || p.M % pt::BM != 0 || p.nk % 9 != 0) return false;
     for (int i = 0; i < p.nseg; ++i)
         if (p.seg[i].ntaps != 9) return false;
     const int W = p.Wo, HW = p.Ho * p.Wo;
-    if (W % 8 != 0 || pt::BM % W != 0) return false;
-    if (!(HW % pt::BM == 0 || pt::BM % HW == 0)) return false;
-    const int seg_px = HW >= pt::BM ? pt::BM : HW;
-    const int patch_rows = (pt::BM / seg_px) * (seg_px / W + 2) * W;
-    if (patch_rows > pt::PATCH_ROWS || patch_rows >= (1 << 16)) return false;
+    if (pt::BM % W != 0) {          // 2-D tiles: 10 image rows x 32 columns
+        if (W % pt::T2_W != 0 || p.Ho % pt::T2_H != 0) return false;
+    } else {
+        if (W % 8 != 0) return false;
+        if (!(HW % pt::BM == 0 || pt::BM % HW == 0)) return false;
+        const int seg_px = HW >= pt::BM ? pt::BM : HW;
+        const int patch_rows = (pt::BM / seg_px) * (seg_px / W + 2) * W;
+        if (patch_rows > pt::PATCH_ROWS || patch_rows >= (1 << 16)) return false;
+    }
     return p.splits >= 1 && p.splits <= p.nk / 9;
 }
 
-// Launches the halo-patch conv kernel (EPI_LINEAR; the caller runs the split-K reduce).
-int launch_igemm_patch(const IgemmParams& p, hipStream_t stream) {
+template <int NT, bool T2>
+static int launch_patch_nt(const IgemmParams& p, hipStream_t stream) {
     using namespace pt;
-    LAVIE_CHECK(igemm_patch_eligible(p), "igemm_patch: conv geometry not supported by the halo-patch kernel");
-    auto kern = g_patch_stamp == 1 ? igemm_patch_kernel<EPI_LINEAR, 1> : g_patch_stamp == 2 ? igemm_patch_kernel<EPI_LINEAR, 2>
-                : g_patch_stamp == 3 ? igemm_patch_kernel<EPI_LINEAR, 3> : g_patch_stamp == 4 ? igemm_patch_kernel<EPI_LINEAR, 4>
-                : g_patch_stamp == 5 ? igemm_patch_kernel<EPI_LINEAR, 5> : igemm_patch_kernel<EPI_LINEAR, 0>;
+    constexpr int BN = 2 * NT * 16;
+    auto kern = g_patch_stamp == 1 ? igemm_patch_kernel<EPI_LINEAR, 1, NT, T2> : g_patch_stamp == 2 ? igemm_patch_kernel<EPI_LINEAR, 2, NT, T2>
+                : g_patch_stamp == 3 ? igemm_patch_kernel<EPI_LINEAR, 3, NT, T2> : g_patch_stamp == 4 ? igemm_patch_kernel<EPI_LINEAR, 4, NT, T2>
+                : g_patch_stamp == 5 ? igemm_patch_kernel<EPI_LINEAR, 5, NT, T2> : igemm_patch_kernel<EPI_LINEAR, 0, NT, T2>;
     static bool attr_set = false;
     if (!attr_set) {
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 0, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 1, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 2, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 3, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 4, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 5, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     const int grid = (p.M / BM) * (p.N / BN);
@@ -369,6 +408,14 @@ int launch_igemm_patch(const IgemmParams& p, hipStream_t stream) {
     else hipLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(THREADS), LDS_BYTES, stream, p);
     LAVIE_HIP(hipGetLastError());
     return 0;
+}
+
+// Launches the halo-patch conv kernel (EPI_LINEAR; the caller runs the split-K reduce).
+int launch_igemm_patch(const IgemmParams& p, hipStream_t stream) {
+    LAVIE_CHECK(igemm_patch_eligible(p), "igemm_patch: conv geometry not supported by the halo-patch kernel");
+    const bool t2 = pt::BM % p.Wo != 0;
+    if (igemm_patch_bn(p.N) == 160) return t2 ? launch_patch_nt<5, true>(p, stream) : launch_patch_nt<5, false>(p, stream);
+    return t2 ? launch_patch_nt<4, true>(p, stream) : launch_patch_nt<4, false>(p, stream);
 }
 
 }  // namespace lavie

@@ -126,6 +126,11 @@ def test_conv3x3_concat_shortcut_temb(ops):
     (8, 128, 0, 160, 5, 8, 0),       # eight 5x8 frames per tile (the model's deepest level)
     (2, 64, 64, 160, 20, 16, 0),     # channel concat of two sources, one frame per tile
     (1, 192, 0, 320, 10, 64, 3),     # W = 64: five image rows per tile, split-K = 3 over three slabs
+    (2, 64, 0, 128, 10, 64, 0),      # 128-wide column tile (the VSR widths), whole-row tiles
+    (1, 128, 0, 256, 20, 128, 0),    # 2-D tiles of 10 rows x 32 columns (rows wider than a tile), 128-wide column tiles
+    (2, 64, 64, 256, 10, 96, 2),     # 2-D tiles, channel concat, split-K over the two slabs, three tiles per image row
+    (1, 64, 0, 160, 30, 32, 0),      # 2-D geometry is not needed here (W = 32 divides 320): still the row tiles
+    (1, 64, 0, 320, 10, 512, 0),     # the VSR stage's 512-pixel rows, 160-wide column tiles
 ])
 def test_conv3x3_halo_patch_kernel(ops, n, c1, c2, cout, h, w, splits):
     """The 320x160 halo-patch conv kernel (igemm_patch.hip) forced on shapes it accepts, with bias, per-video bias

@@ -10,6 +10,9 @@ lib = _lib.load()
 cases = [(32, 40, 64, 320, 0, 320, 0), (32, 40, 64, 640, 320, 320, 0), (32, 40, 64, 640, 0, 320, 0), (32, 20, 32, 640, 0, 640, 0),
          (32, 20, 32, 1280, 640, 640, 0), (32, 20, 32, 320, 0, 640, 0), (32, 10, 16, 1280, 0, 1280, 2), (32, 10, 16, 1280, 1280, 1280, 2),
          (32, 5, 8, 1280, 0, 1280, 8), (32, 5, 8, 1280, 0, 1280, 4)]
+if os.environ.get("PATCH_VSR"):      # the VSR stage's levels: 16 frames (batch 2 x 8) at 320x512 / 160x256 / 80x128 / 40x64
+    cases = [(16, 320, 512, 256, 0, 256, 0), (16, 320, 512, 512, 0, 256, 0), (16, 160, 256, 512, 0, 512, 0), (16, 160, 256, 1024, 0, 512, 0),
+             (16, 80, 128, 1024, 0, 1024, 0), (16, 40, 64, 1024, 0, 1024, 0)]
 for ni, h, w, c1, c2, cout, s5 in cases:
     x1 = rnd(ni * h * w, c1)
     x2 = rnd(ni * h * w, c2) if c2 else None
