@@ -394,9 +394,13 @@ static int pp_plan(int M, int N, int nk, int epilogue) {
 // ---- 320x160 halo-patch conv kernel (igemm_patch.hip): 5-8 % faster than the ping-pong kernel on the convs it accepts
 // (tools/check_patch.py); same grid rule with its own tile: one workgroup per CU, last round at least 85 % full,
 // split-K (over whole slabs) only with at least 45 K-tiles per split.
-static bool patch_fits(int M, int N, int nk, int s) {
-    const int bn = igemm_patch_bn(N);
-    if (M % 320 != 0 || bn == 0 || nk % 9 != 0 || s < 1 || s > nk / 9) return false;
+static bool patch_fits(int M, int N, int nk, int s, int ntaps = 9) {
+    // temporal convs (ntaps 3 / 5): the 128-wide tile only, and only from 1024 channels on — tools/bench_ops.py tconv measured
+    // the temporal mode equal to the ping-pong kernel within +-5 % at 256 / 512 channels (short K loops: 12 - 40 K-tiles, the
+    // activation tile is staged once per N tile instead of once) and 30 % ahead at 1024
+    if (ntaps != 9 && N < 1024) return false;
+    const int bn = ntaps == 9 ? igemm_patch_bn(N) : (N % 128 == 0 ? 128 : 0);
+    if (M % 320 != 0 || bn == 0 || nk % ntaps != 0 || s < 1 || s > nk / ntaps) return false;
     if (s > 1 && nk / s < 45) return false;
     const double r = (double)(M / 320) * (N / bn) * s / 256.0;
     return r / ceil(r) >= 0.85;
@@ -411,7 +415,7 @@ int igemm_plan_splits_gather(const IgemmParams& p) {
         IgemmParams q = p;
         for (int s = 1; s <= 4; ++s) {
             q.splits = s;
-            if (patch_fits(p.M, p.N, p.nk, s) && igemm_patch_eligible(q)) return s;
+            if (patch_fits(p.M, p.N, p.nk, s, p.tframes > 0 ? p.seg[0].ntaps : 9) && igemm_patch_eligible(q)) return s;
         }
     }
     return plan_splits(p.M, p.N, p.nk, EPI_LINEAR, false);
@@ -556,7 +560,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     }
     if (!gather && ppx_plan(p, epilogue)) return launch_igemm_ppx(p, epilogue, stream);
     // halo-patch conv kernel: forced (mode 5) or whenever its grid rule holds at this split factor
-    if (gather && igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits)))) {
+    if (gather && igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)))) {
         if (int rc = launch_igemm_patch(p, stream)) return rc;
         return reduce_splits();
     }

@@ -54,7 +54,9 @@ static_assert(T2_W * T2_H == BM && T2_ROWS <= PATCH_ROWS && T2_W % 16 == 0, "2-D
 __device__ unsigned long long g_patch_stamps[8 * 16];
 
 // NT = 16-column blocks per wave: 5 -> 320x160 tile (every channel count of the base model), 4 -> 320x128 (the VSR widths)
-template <int EPI, int STAMP = 0, int NT = 5, bool T2 = false>
+// MODE 0: tiles of whole image rows; 1: 2-D tiles (10 rows x 32 columns); 2: temporal (T,1,1) convolution, tile = every frame of
+// 320 / F pixels (no halo at all: tap t of a row is the same pixel t - T/2 frames away, inside the tile or outside the clip)
+template <int EPI, int STAMP = 0, int NT = 5, int MODE = 0>
 __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const IgemmParams p) {
     using namespace pt;
     constexpr int BN = 2 * NT * 16, W_BYTES = BN * 128;
@@ -79,18 +81,24 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int split = blockIdx.y;
-    const int nslab = p.nk / 9;
+    const int ntap = MODE == 2 ? __builtin_amdgcn_readfirstlane(p.seg[0].ntaps) : 9;       // K-tiles per 64-channel slab
+    const int nslab = p.nk / ntap;
     const int slab_begin = (int)((long)nslab * split / p.splits);
     const int slab_end = (int)((long)nslab * (split + 1) / p.splits);
-    const int t_begin = slab_begin * 9, t_end = slab_end * 9;
+    const int t_begin = slab_begin * ntap, t_end = slab_end * ntap;
+    // patch pieces of the NEXT slab staged per K-tile and wave: the whole patch must have landed one K-tile before the slab
+    // ends.  3x3: 56 pieces, one per wave over 7 of the 9 K-tiles; temporal: 40 pieces (320 rows), two (T = 5) or three (T = 3)
+    const int npieces = MODE == 2 ? BM / 8 : PATCH_PIECES;
+    const int ppk = MODE == 2 ? (ntap >= 5 ? 2 : 3) : 1;
 
     const int lr = lane >> 3;
     const int kofs = ((lane & 7) ^ lr) * 8;         // source K offset (halfs) after the slot swizzle
     auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
     // ---- tile geometry: 320 pixels = `rows_seg` image rows of each of `nf` frame segments, or (t2) 10 rows x 32 columns
-    const int Wd = p.Wo, Hd = p.Ho, HW = Hd * Wd;
-    constexpr bool t2 = T2;                         // the launcher instantiates T2 exactly when BM % Wd != 0
+    const int Wd = MODE == 2 ? BM : p.Wo, Hd = MODE == 2 ? 1 : p.Ho, HW = Hd * Wd;      // (unused in temporal mode)
+    constexpr bool t2 = MODE == 1;                  // the launcher instantiates MODE 1 exactly when BM % Wd != 0
+    constexpr bool tmode = MODE == 2;
     const int seg_px = HW >= BM ? BM : HW;          // pixels of one frame segment inside the tile
     const int rows_seg = seg_px / Wd;
     const int PF = (rows_seg + 2) * Wd;             // patch rows of one segment (with the two halo image rows)
@@ -106,8 +114,16 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
 
     int* ptab = reinterpret_cast<int*>(smem + PTAB);
     int* segtab = reinterpret_cast<int*>(smem + SEGTAB);
+    // tmode: tile row r = (frame r / PX, pixel tp0 + r % PX) of video tb, PX = 320 / F pixels
+    const int tF = tmode ? p.tframes : 1, tD = tmode ? p.tpix : 1;
+    const int PX = BM / tF;
+    const int tb = tmode ? tile_m / (tD / PX) : 0;
+    const int tp0 = tmode ? (tile_m - tb * (tD / PX)) * PX : 0;
+    auto trow = [&](int r) { return (tb * tF + r / PX) * tD + tp0 + (r - (r / PX) * PX); };
     for (int j = tid; j < PATCH_ROWS; j += THREADS) {
-        if (t2) {
+        if (tmode) {
+            ptab[j] = j < BM ? trow(j) : -1;
+        } else if (t2) {
             const int py = j / T2_PW, px = j - py * T2_PW;
             const int yy = ty0 - 1 + py, xx = tx0 - 1 + px;
             const bool ok = j < T2_ROWS && (unsigned)yy < (unsigned)Hd && (unsigned)xx < (unsigned)Wd;
@@ -127,7 +143,10 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
             const int tap = idx / BM, r = idx - tap * BM;
             const int dy = tap / 3, dx = tap - dy * 3;
             int u;
-            if (t2) {                                       // halo columns are part of the patch: no wrap-around case
+            if (tmode) {                                    // frame tap: the same pixel (tap - T/2) frames away, or zeros
+                const int ff = r / PX + tap - (ntap >> 1);
+                u = (tap < ntap && (unsigned)ff < (unsigned)tF) ? ff * PX + (r - (r / PX) * PX) : PATCH_ROWS;
+            } else if (t2) {                                // halo columns are part of the patch: no wrap-around case
                 u = (r / T2_W + dy) * T2_PW + (r % T2_W) + dx;
             } else {
                 const int f = r / seg_px, rr = r - f * seg_px;
@@ -294,12 +313,23 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         const int wst = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
         const bool next_slab = slab + 1 < slab_end;
-        const int piece = kt * 8 + wave;            // patch piece of the next slab this wave stages during this K-tile
-        const bool pissue = next_slab && piece < PATCH_PIECES;
-        // ---- R(t, 0): fragments, two weight pieces of K-tile t+1, the pixel of this K-tile's patch piece
+        // patch pieces of the next slab this wave stages during this K-tile: (kt * ppk + j) * 8 + wave, j < ppk
+        int piece[3], pix[3];
+        bool pissue[3];
+        int nissue = 0;                             // wave-uniform AND the same for all eight waves (npieces % 8 == 0)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            piece[j] = (kt * ppk + j) * 8 + wave;
+            pissue[j] = (MODE == 2 || j == 0) && j < ppk && next_slab && piece[j] < npieces;
+            nissue += pissue[j] ? 1 : 0;
+        }
+        // ---- R(t, 0): fragments, two weight pieces of K-tile t+1, the pixels of this K-tile's patch pieces
         read_frags(wst, 0, af0, wf0);
-        int pix = -1;
-        if (pissue) pix = ptab[piece * 8 + lr];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            pix[j] = -1;
+            if (pissue[j]) pix[j] = ptab[piece[j] * 8 + lr];
+        }
         if (more && STAMP != 2) issue_w01(t + 1, wst ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(1);
@@ -310,12 +340,14 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         stamp(3);
         bar();
         stamp(4);
-        // ---- R(t, 1): fragments, the third weight piece, one patch piece of the next slab, next tap's table entries
+        // ---- R(t, 1): fragments, the third weight piece, the patch pieces of the next slab, next tap's table entries
         read_frags(wst, 1, af0, wf0);
-        const bool wrap = kt == 8;
+        const bool wrap = kt == ntap - 1;
         tap_read(wrap ? 0 : kt + 1);
         if (more && STAMP != 2) issue_w2(t + 1, wst ^ 1);
-        if (pissue && STAMP != 3) issue_patch(piece, pb ^ 1, pix);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (pissue[j] && STAMP != 3) issue_patch(piece[j], pb ^ 1, pix[j]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         tap_finish(wrap ? pb ^ 1 : pb);
         stamp(6);
@@ -324,13 +356,15 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         // ---- M(t, 1)
         mfma_block(af0, wf0);
         stamp(8);
-        // this wave's weight pieces of K-tile t+1 have landed (the patch piece issued after them may still fly)
-        if (pissue) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's weight pieces of K-tile t+1 have landed (the patch pieces issued after them may still fly)
+        if (nissue == 0 || STAMP == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nissue == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (nissue == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         stamp(9);
         if (!(grp == 1 && !more)) bar();
         stamp(10);
-        if (++kt == 9) {
+        if (++kt == ntap) {
             kt = 0;
             pb ^= 1;
             ++slab;
@@ -345,7 +379,10 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
             g_patch_stamps[wave * 16 + 11] = (unsigned long long)(t_end - t_begin);
         }
     }
-    if constexpr (t2) {       // slice mt of wave row wm = 16 pixels of image row ty0 + (5 wm + mt) / 2, columns tx0 + 16 ((5 wm + mt) & 1) ..
+    if constexpr (tmode) {
+        igemm_epilogue_rows<MT, NT, EPI>(p, acc, [&](int mt) { return trow(wm * (MT * 16) + mt * 16 + (lane & 15)); },
+                                         n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);
+    } else if constexpr (t2) {       // slice mt of wave row wm = 16 pixels of image row ty0 + (5 wm + mt) / 2, columns tx0 + 16 ((5 wm + mt) & 1) ..
         const int rbase = (frame0 * Hd + ty0) * Wd + tx0 + (lane & 15);
         igemm_epilogue_rows<MT, NT, EPI>(p, acc, [=](int mt) { const int r16 = 5 * wm + mt; return rbase + (r16 >> 1) * Wd + (r16 & 1) * 16; },
                                          n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);
@@ -365,9 +402,23 @@ int igemm_patch_read_stamps(unsigned long long* out) {
 // Column-tile width the halo-patch kernel uses for N output channels: 160 (base widths), 128 (VSR widths), 0 = none.
 int igemm_patch_bn(int N) { return N % 160 == 0 ? 160 : N % 128 == 0 ? 128 : 0; }
 
+// Temporal (T,1,1) convolution the kernel's MODE 2 accepts: every segment T = 3 or 5 frame taps, a tile = all F frames of
+// 320 / F pixels (F | 320, pixels per frame a multiple of 320 / F), 128-wide column tiles.
+static bool patch_temporal_ok(const IgemmParams& p) {
+    if (p.tframes <= 0 || p.nseg < 1) return false;
+    const int T = p.seg[0].ntaps;
+    if (T != 3 && T != 5) return false;
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.seg[i].ntaps != T) return false;
+    if (pt::BM % p.tframes != 0 || p.tpix % (pt::BM / p.tframes) != 0 || p.N % 128 != 0 || p.M % pt::BM != 0 || p.nk % T != 0) return false;
+    return p.splits >= 1 && p.splits <= p.nk / T;
+}
+
 // Whether the halo-patch kernel can run this conv (geometry only; the caller decides on grid fill and split-K).
 bool igemm_patch_eligible(const IgemmParams& p) {
-    if (p.stride != 1 || p.ups != 0 || igemm_patch_bn(p.N) == 0 || p.M % pt::BM != 0 || p.nk % 9 != 0) return false;
+    if (p.stride != 1 || p.ups != 0) return false;
+    if (p.tframes > 0) return patch_temporal_ok(p);
+    if (igemm_patch_bn(p.N) == 0 || p.M % pt::BM != 0 || p.nk % 9 != 0) return false;
     for (int i = 0; i < p.nseg; ++i)
         if (p.seg[i].ntaps != 9) return false;
     const int W = p.Wo, HW = p.Ho * p.Wo;
@@ -383,26 +434,26 @@ bool igemm_patch_eligible(const IgemmParams& p) {
     return p.splits >= 1 && p.splits <= p.nk / 9;
 }
 
-template <int NT, bool T2>
+template <int NT, int MODE>
 static int launch_patch_nt(const IgemmParams& p, hipStream_t stream) {
     using namespace pt;
     constexpr int BN = 2 * NT * 16;
-    auto kern = g_patch_stamp == 1 ? igemm_patch_kernel<EPI_LINEAR, 1, NT, T2> : g_patch_stamp == 2 ? igemm_patch_kernel<EPI_LINEAR, 2, NT, T2>
-                : g_patch_stamp == 3 ? igemm_patch_kernel<EPI_LINEAR, 3, NT, T2> : g_patch_stamp == 4 ? igemm_patch_kernel<EPI_LINEAR, 4, NT, T2>
-                : g_patch_stamp == 5 ? igemm_patch_kernel<EPI_LINEAR, 5, NT, T2> : igemm_patch_kernel<EPI_LINEAR, 0, NT, T2>;
+    auto kern = g_patch_stamp == 1 ? igemm_patch_kernel<EPI_LINEAR, 1, NT, MODE> : g_patch_stamp == 2 ? igemm_patch_kernel<EPI_LINEAR, 2, NT, MODE>
+                : g_patch_stamp == 3 ? igemm_patch_kernel<EPI_LINEAR, 3, NT, MODE> : g_patch_stamp == 4 ? igemm_patch_kernel<EPI_LINEAR, 4, NT, MODE>
+                : g_patch_stamp == 5 ? igemm_patch_kernel<EPI_LINEAR, 5, NT, MODE> : igemm_patch_kernel<EPI_LINEAR, 0, NT, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 0, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 1, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 2, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 3, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 4, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 5, NT, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 0, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 1, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 2, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 3, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 4, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 5, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     const int grid = (p.M / BM) * (p.N / BN);
     const double K = (double)p.nk * IGEMM_BK;
-    ProfileScope prof(KC_CONV_PATCH, stream, 2.0 * p.M * p.N * K, 2.0 * ((double)p.M * K / 9.0 + (double)p.N * K + (double)p.M * p.N),
+    ProfileScope prof(KC_CONV_PATCH, stream, 2.0 * p.M * p.N * K, 2.0 * ((double)p.M * K / (MODE == 2 ? p.seg[0].ntaps : 9.0) + (double)p.N * K + (double)p.M * p.N),
                       /*kernel_events=*/true);
     if (prof.active()) hipExtLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(THREADS), LDS_BYTES, stream, prof.start(), prof.stop(), 0, p);
     else hipLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(THREADS), LDS_BYTES, stream, p);
@@ -413,9 +464,10 @@ static int launch_patch_nt(const IgemmParams& p, hipStream_t stream) {
 // Launches the halo-patch conv kernel (EPI_LINEAR; the caller runs the split-K reduce).
 int launch_igemm_patch(const IgemmParams& p, hipStream_t stream) {
     LAVIE_CHECK(igemm_patch_eligible(p), "igemm_patch: conv geometry not supported by the halo-patch kernel");
+    if (p.tframes > 0) return launch_patch_nt<4, 2>(p, stream);
     const bool t2 = pt::BM % p.Wo != 0;
-    if (igemm_patch_bn(p.N) == 160) return t2 ? launch_patch_nt<5, true>(p, stream) : launch_patch_nt<5, false>(p, stream);
-    return t2 ? launch_patch_nt<4, true>(p, stream) : launch_patch_nt<4, false>(p, stream);
+    if (igemm_patch_bn(p.N) == 160) return t2 ? launch_patch_nt<5, 1>(p, stream) : launch_patch_nt<5, 0>(p, stream);
+    return t2 ? launch_patch_nt<4, 1>(p, stream) : launch_patch_nt<4, 0>(p, stream);
 }
 
 }  // namespace lavie

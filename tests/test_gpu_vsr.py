@@ -42,6 +42,41 @@ def test_temporal_conv_vs_oracle(shape, taps):
     assert rel_l2(from_rows(y0.float().cpu(), b, frames, 1, d), V.temporal_conv(x, w, bias)) < TOL_OP
 
 
+@pytest.mark.parametrize("taps", [3, 5])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 8, 80), (1, 192, 256, 5, 128), (2, 128, 128, 4, 160), (1, 64, 128, 16, 60)])
+def test_temporal_conv_patch_kernel(shape, taps):
+    """The halo-patch kernel's temporal mode (a tile = every frame of 320 / F pixels, staged once per 64-channel slab and
+    re-read at the T frame taps) forced on shapes it accepts — F = 8 / 5 / 4 / 16, two videos (frame 0 of video 1 must read
+    zeros, not video 0), bias + per-video bias + residual, split-K over slabs — against the oracle and, bit for bit, against
+    the default kernel."""
+    from lavie_amd import _lib, ops
+    from oracle import vsr_blocks as V
+    lib = _lib.load()
+    b, cin, cout, frames, d = shape
+    g = torch.Generator().manual_seed(cin + cout + frames + taps + 1)
+    x = torch.randn(b, cin, frames, 1, d, generator=g).half().float()
+    w = (torch.randn(cout, cin, taps, 1, 1, generator=g) / (cin * taps) ** 0.5).half().float()
+    bias = torch.randn(cout, generator=g)
+    bias2 = torch.randn(b, cout, generator=g)
+    res = torch.randn(b, cout, frames, 1, d, generator=g).half().float()
+    ref = V.temporal_conv(x, w, bias) + bias2[:, :, None, None, None] + res
+    wp = ops.pack_temporal_conv(h16(w))
+    args = dict(bias2=f32(bias2), residual=h16(to_rows(res)))
+    y_auto = ops.temporal_conv(h16(to_rows(x)), wp, f32(bias), b, frames, d, taps, **args)
+    outs = []
+    try:
+        for splits in (0, cin // 64 if cin > 64 else 0):
+            lib.lavie_debug_force_tile(5)
+            lib.lavie_debug_force_splits(splits)
+            outs.append(ops.temporal_conv(h16(to_rows(x)), wp, f32(bias), b, frames, d, taps, **args))
+    finally:
+        lib.lavie_debug_force_tile(0)
+        lib.lavie_debug_force_splits(0)
+    assert rel_l2(from_rows(outs[0].float().cpu(), b, frames, 1, d), ref) < TOL_OP
+    assert torch.equal(outs[0], y_auto)                   # same summation order as the other kernels
+    assert rel_l2(from_rows(outs[1].float().cpu(), b, frames, 1, d), ref) < TOL_OP
+
+
 def test_vsr_resnet_block_3dcnn_golden():
     """ResnetBlock3DCNN (vsr/models/resnet.py:220-315) composed from the C-ABI operators: video-domain GroupNorm + SiLU,
     temporal conv with the time-embedding projection as per-video bias, GroupNorm + SiLU, temporal conv + residual."""

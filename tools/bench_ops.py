@@ -287,10 +287,15 @@ def bench_tconv():
         w = rnd(C, C, taps, 1, 1) / math.sqrt(C * taps)
         wp = ops.pack_temporal_conv(w)
         bias = torch.randn(C, device=dev)
-        us = timeit(lambda: ops.temporal_conv(x, wp, bias, 1, F_, D, taps), iters=10)
         fl = 2.0 * F_ * D * C * C * taps
         by = 2.0 * 2 * F_ * D * C
-        print(f"{1:>2} {F_:>3} {D:>7} {C:>5} {taps:>4} | {us:9.1f} {fl / us / 1e6:6.0f} {by / us / 1e3:6.0f}")
+        row = f"{1:>2} {F_:>3} {D:>7} {C:>5} {taps:>4} | "
+        for mode in (0, 3):                     # automatic choice (the halo-patch kernel's temporal mode) / ping-pong kernel forced
+            _lib.load().lavie_debug_force_tile(mode)
+            us = timeit(lambda: ops.temporal_conv(x, wp, bias, 1, F_, D, taps), iters=10)
+            row += f"mode {mode}: {us:9.1f} {fl / us / 1e6:6.0f} {by / us / 1e3:6.0f} | "
+        _lib.load().lavie_debug_force_tile(0)
+        print(row)
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tconv":
