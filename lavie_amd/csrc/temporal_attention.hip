@@ -275,9 +275,9 @@ __device__ __attribute__((aligned(16))) half_t g_tmp_dump_page[64 * 8];
 // workgroups per CU.  NT = 4 (clips of 17..64 frames, the 61-frame interpolation model): 160-channel head groups (4 / 2 / 1
 // heads), 68 KiB tile buffers, one workgroup per CU; the work items of a tile are (head, 16-query block) pairs so the four
 // waves of a head share its query blocks (eight waves: 2 / 4 / 8 per head).
-template <int NT>
+template <int NT, int RLv = (NT == 1 ? 320 : 160)>
 struct Tdma {
-    static constexpr int RL = NT == 1 ? 320 : 160;          // channels per row segment
+    static constexpr int RL = RLv;                          // channels per row segment: 320 / 160 (base widths), 256 / 128 (VSR widths)
     static constexpr int CPR = RL / 8;                      // real 16-byte chunks per row
     static constexpr int RCH = CPR + 2;                     // chunks per LDS row: 672 / 352 B = 32 B x odd
     static constexpr int RS = RCH * 16;
@@ -296,13 +296,17 @@ struct Tdma {
     static constexpr int MAXH = NT == 1 ? 2 : 1;            // heads per wave (8 heads on 4 waves / at most 4 heads on 8 waves)
     static constexpr int MAXQ = NT == 1 ? 1 : 2;            // 16-query blocks per wave and head
 };
-static_assert(Tdma<4>::LDS_BYTES <= 160 * 1024 && Tdma<1>::LDS_BYTES * 2 <= 160 * 1024 && Tdma<4>::CHUNKS % 64 == 0, "temporal stream tiles do not fit LDS");
+static_assert(Tdma<4>::LDS_BYTES <= 160 * 1024 && Tdma<1>::LDS_BYTES * 2 <= 160 * 1024 && Tdma<4>::CHUNKS % 64 == 0 &&
+              Tdma<4, 128>::LDS_BYTES <= 160 * 1024 && Tdma<1, 256>::LDS_BYTES * 2 <= 160 * 1024, "temporal stream tiles do not fit LDS");
 
 template <int N> __device__ __forceinline__ void tdma_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NT>
-__global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_stream_kernel(const TemporalParams p, const int ngroups, const int tiles_per_group) {
-    using T = Tdma<NT>;
+// PACK = 2 (NT = 1, clips of <= 8 frames: the VSR stage's 8-frame chunks): the 16 rows of a tile are TWO neighbouring pixels x 8
+// frames (row = 8 * pixel + frame) instead of one pixel x 16 frames half of which would be zero rows; scores between the two
+// pixels are masked, so the probabilities are block diagonal and P V stays one MFMA.
+template <int NT, int RLv, int PACK = 1>
+__global__ __launch_bounds__((Tdma<NT, RLv>::NW * 64), (Tdma<NT, RLv>::OCC)) void temporal_stream_kernel(const TemporalParams p, const int ngroups, const int tiles_per_group) {
+    using T = Tdma<NT, RLv>;
     constexpr int RL = T::RL, CPR = T::CPR, RCH = T::RCH, RS = T::RS, FP = T::FP, CHUNKS = T::CHUNKS, PIECES = T::PIECES,
                   BUF_BYTES = T::BUF_BYTES, STORES = T::STORES, NW = T::NW, MAXH = T::MAXH, MAXQ = T::MAXQ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -312,6 +316,8 @@ __global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_str
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int F = p.F, dh = p.dh;
+    static_assert(PACK == 1 || NT == 1, "pixel packing is for single-block clips");
+    const int Dt = p.D / PACK;                      // tiles per video
     const int C = p.heads * dh;
     const int HG = RL / dh;
     // work split inside a tile: more heads than waves -> wave w takes heads w, w + NW, ... with every query block;
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_str
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int f = t * 16 + li, k = 4 * g + j;
+            const int f = PACK == 2 ? (li & 7) : t * 16 + li, k = 4 * g + j;
             const bool ok = f < F && k < rpairs;
             rc[t][j] = ok ? p.rot_cos[f * rpairs + k] : 1.f;
             rs[t][j] = ok ? p.rot_sin[f * rpairs + k] : 0.f;
@@ -347,13 +353,13 @@ __global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_str
         for (int qi = 0; qi < MAXQ; ++qi) {
             const int h = h0 + hi * hstep, qt = q0 + qi * qstep;
             const bool have = h < HG && qt < NT;
-            const int qidx = qt * 16 + li;
+            const int qidx = PACK == 2 ? (li & 7) : qt * 16 + li;
             const int qic = qidx < F ? qidx : F - 1;
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kj = kt * 16 + 4 * g + r;
+                    const int kj = PACK == 2 ? ((4 * g + r) & 7) : kt * 16 + 4 * g + r;
                     const int kc = kj < F ? kj : F - 1;
                     bias[hi][qi][kt][r] = have ? p.bias[((size_t)(hg * HG + h) * F + qic) * F + kc] : 0.f;
                 }
@@ -365,8 +371,9 @@ __global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_str
     for (int i = 0; i < PIECES; ++i) {
         const int chunk = (wave + NW * i) * 64 + lane;
         const int row = chunk / RCH, c = chunk - row * RCH;
-        const int a = row / FP, f = row - a * FP;
-        goff[i] = (chunk < CHUNKS && c < CPR && f < F) ? ((long)f * p.D * p.ld + a * C + c * 8) : -1;
+        const int a = row / FP, rr = row - a * FP;
+        const int f = PACK == 2 ? (rr & 7) : rr, pxl = PACK == 2 ? (rr >> 3) : 0;
+        goff[i] = (chunk < CHUNKS && c < CPR && f < F) ? ((long)f * p.D * p.ld + (long)pxl * p.ld + a * C + c * 8) : -1;
     }
     // the loads above are consumed here, not inside the loop (a tracked load in flight there would cost a vmcnt(0))
 #pragma unroll
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_str
 
     auto tile_base = [&](int n) -> const half_t* {          // token row of (b, frame 0, pixel) of tile n, this head group
         const int t = t0 + n * tstride;
-        const int b = t / p.D, pix = t - b * p.D;
+        const int b = t / Dt, pix = (t - b * Dt) * PACK;
         return p.qkv + ((size_t)b * F * p.D + pix) * p.ld + col0;
     };
     auto issue_tile = [&](int n, int buf) {
@@ -487,7 +494,9 @@ __global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_str
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = -INFINITY;
-                        if (kt * 16 + 4 * g + r < F) v = (s[kt][r] + bias[hi][qi][kt][r]) * l2e;
+                        const int kj = kt * 16 + 4 * g + r;
+                        const bool valid = PACK == 2 ? ((kj & 7) < F && (kj >> 3) == (li >> 3)) : kj < F;
+                        if (valid) v = (s[kt][r] + bias[hi][qi][kt][r]) * l2e;
                         s[kt][r] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -544,17 +553,18 @@ __global__ __launch_bounds__(Tdma<NT>::NW * 64, Tdma<NT>::OCC) void temporal_str
         // ---- whole output rows (640 / 320 bytes): wave w stores chunks STORES * 64 * w .. of the FP x CPR
         {
             const int t = t0 + n * tstride;
-            const int b = t / p.D, pix = t - b * p.D;
+            const int b = t / Dt, pix = (t - b * Dt) * PACK;
             half_t* obase = p.o + ((size_t)b * F * p.D + pix) * p.ldo + col0;
 #pragma unroll
             for (int i = 0; i < STORES; ++i) {
                 const int id = (wave * STORES + i) * 64 + lane;
-                const int f = id / CPR, c = id - f * CPR;
+                const int rr = id / CPR, c = id - rr * CPR;
+                const int f = PACK == 2 ? (rr & 7) : rr, pxl = PACK == 2 ? (rr >> 3) : 0;
                 const bool act = id < FP * CPR && f < F;
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(obuf + (act ? f * RS + c * 16 : 0));
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(obuf + (act ? rr * RS + c * 16 : 0));
                 // lanes without a row write their 16 bytes to a dump page instead: the instruction always issues, so the counted
                 // waits above see exactly STORES stores per wave and tile
-                half_t* dst = act ? obase + (size_t)f * p.D * p.ldo + c * 8 : g_tmp_dump_page + lane * 8;
+                half_t* dst = act ? obase + ((size_t)f * p.D + pxl) * p.ldo + c * 8 : g_tmp_dump_page + lane * 8;
                 asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
             }
         }
@@ -578,24 +588,34 @@ int launch_temporal_attention(const TemporalParams& p, hipStream_t stream) {
     ProfileScope prof(KC_TEMPORAL, stream, 4.0 * tok * p.F * width, 4.0 * tok * width * 2.0, /*kernel_events=*/true);
     const int NT = cdiv(p.F, 16) <= 1 ? 1 : 4;
     const int FP = NT * 16;
-    // streaming kernel: head groups of 320 (<= 16 frames) or 160 (<= 64 frames) channels must tile the width (dh 40 / 80 / 160)
-    const int srl = NT == 1 ? 320 : 160;
-    if (g_temporal_budget == 0 && srl % p.dh == 0 && (p.heads * p.dh) % srl == 0 && srl / p.dh <= 8 &&
-        (double)p.F * p.D * p.ld * 2.0 < 2.0e9 && (double)p.F * p.D * p.ldo * 2.0 < 4.0e9) {
+    // streaming kernel: head groups of 320 / 256 (<= 16 frames) or 160 / 128 (<= 64 frames) channels must tile the width
+    // (base widths: head dims 40 / 80 / 160; VSR widths: 32 / 64 / 128)
+    const int Cw = p.heads * p.dh;
+    const int wide = NT == 1 ? 320 : 160, narrow = NT == 1 ? 256 : 128;
+    const int srl = (Cw % wide == 0 && wide % p.dh == 0) ? wide : (Cw % narrow == 0 && narrow % p.dh == 0) ? narrow : 0;
+    if (g_temporal_budget == 0 && srl != 0 && srl / p.dh <= 8) {       // (all offsets inside the kernel are 64-bit)
         static bool attr = false;
         if (!attr) {
-            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<1>::LDS_BYTES));
-            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<4>::LDS_BYTES));
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<1, 320>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<1, 320>::LDS_BYTES));
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<1, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<1, 256>::LDS_BYTES));
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<1, 320, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<1, 320>::LDS_BYTES));
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<1, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<1, 256>::LDS_BYTES));
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<4, 160>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<4, 160>::LDS_BYTES));
+            LAVIE_HIP(hipFuncSetAttribute((const void*)temporal_stream_kernel<4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, Tdma<4, 128>::LDS_BYTES));
             attr = true;
         }
-        const int ngroups = p.heads * p.dh / srl;
-        const int tiles_per_group = p.B * p.D;
+        const bool pack2 = NT == 1 && p.F <= 8 && p.D % 2 == 0;      // two pixels x 8 frames per 16-row tile
+        const int ngroups = Cw / srl;
+        const int tiles_per_group = p.B * (pack2 ? p.D / 2 : p.D);
         int per_group = (NT == 1 ? 512 : 256) / ngroups;     // two / one workgroup per CU
         if (per_group < 1) per_group = 1;
         if (per_group > tiles_per_group) per_group = tiles_per_group;
         const int grid = per_group * ngroups;
-        const int lds = NT == 1 ? Tdma<1>::LDS_BYTES : Tdma<4>::LDS_BYTES;
-        auto kern = NT == 1 ? temporal_stream_kernel<1> : temporal_stream_kernel<4>;
+        const int lds = NT == 1 ? (srl == 320 ? Tdma<1, 320>::LDS_BYTES : Tdma<1, 256>::LDS_BYTES)
+                                : (srl == 160 ? Tdma<4, 160>::LDS_BYTES : Tdma<4, 128>::LDS_BYTES);
+        auto kern = pack2 ? (srl == 320 ? temporal_stream_kernel<1, 320, 2> : temporal_stream_kernel<1, 256, 2>)
+                    : NT == 1 ? (srl == 320 ? temporal_stream_kernel<1, 320> : temporal_stream_kernel<1, 256>)
+                            : (srl == 160 ? temporal_stream_kernel<4, 160> : temporal_stream_kernel<4, 128>);
         const int threads = NT == 1 ? Tdma<1>::NW * 64 : Tdma<4>::NW * 64;
         if (prof.active()) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, prof.start(), prof.stop(), 0, p, ngroups, tiles_per_group);
         else hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, p, ngroups, tiles_per_group);
