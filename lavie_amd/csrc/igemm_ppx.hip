@@ -146,7 +146,7 @@ __global__ __launch_bounds__(ppx::THREADS, 2) void igemm_ppx_kernel(const IgemmP
     constexpr bool DIRECT = PPX_TRICKLE == 0;             // stores leave from the finish pass itself
     constexpr int TRICKLE = DIRECT ? 1 : PPX_TRICKLE;     // parked stores per R phase
     constexpr int ND = LIN ? NS : MT * NT / 2;            // direct stores per wave and tile (GEGLU: one 8-byte store per pair)
-    constexpr int PHASES = (NS + TRICKLE - 1) / TRICKLE;  // R phases that carry stores: 8, 5, 3 (the launcher wants nk >= 5)
+    [[maybe_unused]] constexpr int PHASES = (NS + TRICKLE - 1) / TRICKLE;  // R phases that carry stores: 8, 5, 3 (the launcher wants nk >= 5)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
