@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_kernel(const IgemmParam
         split = blockIdx.y;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, &tile_m, &tile_n);
+        igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, (long)p.N * p.nk * IGEMM_BK, &tile_m, &tile_n);
     } else {
         // split-K = the weight-bound convolutions of the deep levels (M 1280, K 11520 .. 23040: 30 - 59 MB of weights for
         // 3 MB of activations).  N-fastest order spread the M tiles that share a weight slice over all eight XCDs and every XCD

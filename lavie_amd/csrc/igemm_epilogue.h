@@ -11,13 +11,17 @@ namespace lavie {
 // wide: every M tile then streams the whole weight matrix through the fabric again (PMC, round 2: the L2-level GEGLU GEMM
 // read 869 MB for 39 MB of operands, 5.6 TB/s of fabric traffic under a 154 us kernel).  Wide GEMMs (more than 4 N tiles)
 // therefore run in blocks of 32 ids = mr x nr tiles (8 x 4 or 16 x 2): a round shares nr weight slices and mr activation
-// tiles.  Narrow ones keep N-fastest order (a round = 32 / n_tiles M tiles x all N tiles, which shares the A tiles).
+// tiles (M tiles beyond the last whole block keep N-fastest order: ids >= m_full * n_tiles map to themselves either way).  Narrow ones keep N-fastest order (a round = 32 / n_tiles M tiles x all N tiles, which shares the A tiles).
 #ifndef LAVIE_TILE_BLOCKS
 #define LAVIE_TILE_BLOCKS 1
 #endif
-__device__ __forceinline__ void igemm_tile_of(int id, int m_tiles, int n_tiles, int* mt, int* nt) {
+// `w_halfs` = elements of the whole weight matrix: up to 1 Mi halfs (2 MiB) it stays resident in every XCD's L2 whatever the
+// order, and N-fastest — which streams each activation tile exactly once — is the better choice (PMC: the L0 GEGLU GEMM, 1.6 MB
+// of weights, read 176 MB in blocks and 67 MB N-fastest).
+__device__ __forceinline__ void igemm_tile_of(int id, int m_tiles, int n_tiles, long w_halfs, int* mt, int* nt) {
     const int nr = n_tiles % 4 == 0 ? 4 : 2, mr = 32 / nr;
-    if (!LAVIE_TILE_BLOCKS || n_tiles <= 4 || (n_tiles & 1) || m_tiles % mr != 0) {
+    const int m_full = (m_tiles / mr) * mr;         // M tiles covered by whole blocks; the rest (< mr rows of tiles) runs N-fastest
+    if (!LAVIE_TILE_BLOCKS || n_tiles <= 4 || (n_tiles & 1) || w_halfs <= (1L << 20) || id >= m_full * n_tiles) {
         *mt = id / n_tiles;
         *nt = id - *mt * n_tiles;
         return;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(pp::THREADS, 2) void igemm_pp_kernel(const IgemmPar
         bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
     }
     int tile_m, tile_n;
-    igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, &tile_m, &tile_n);
+    igemm_tile_of(bid, (int)gridDim.x / n_tiles, n_tiles, (long)p.N * p.nk * IGEMM_BK, &tile_m, &tile_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int split = blockIdx.y;
