@@ -226,12 +226,85 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
     }
 }
 
+// Register-weight variant for Cout = 4 (every model here: 4 latent channels): a lane keeps the weights of ITS (tap, 8-channel
+// vector) slots for the four outputs in registers (NV slots x 4 outputs x 16 B) and walks CONV_OUT4_PPW consecutive pixels, so the
+// loop has no LDS traffic at all: per pixel NV independent 16-byte loads, 16 NV v_dot2, four wave reductions.  Same per-lane
+// accumulation order as the kernel above (slot lane, lane + 64, ...), then the same wave_sum: bit-identical results.
+constexpr int CONV_OUT4_PPW = 16;
+template <int NV>
+__global__ __launch_bounds__(256) void conv_out4_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wp,
+                                                       const float* __restrict__ bias, half_t* __restrict__ y, int B,
+                                                       int Cin, int F, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const long M = (long)B * F * H * W;
+    const int nvec = Cin >> 3, kk = 9 * Cin;
+    half8_t wr[NV][4];
+    int dy[NV], dx[NV], co[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        const bool have = i < 9 * nvec;
+        const int tap = have ? i / nvec : 4, vec = have ? i - tap * nvec : 0;
+        dy[j] = have ? tap / 3 - 1 : 1 << 20;       // a slot past the stencil never passes the bounds test
+        dx[j] = tap % 3 - 1;
+        co[j] = vec * 8;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            wr[j][c] = have ? *reinterpret_cast<const half8_t*>(wp + (size_t)c * kk + tap * Cin + vec * 8) : (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
+    const long m_begin = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CONV_OUT4_PPW;
+    for (int pp = 0; pp < CONV_OUT4_PPW; ++pp) {
+        const long m = m_begin + pp;
+        if (m >= M) return;
+        const int xw = (int)(m % W);
+        const int yh = (int)((m / W) % H);
+        const long img = m / ((long)W * H);          // b * F + f
+        half8_t v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int iy = yh + dy[j], ix = xw + dx[j];
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int iyc = ok ? iy : yh, ixc = ok ? ix : xw;           // clamped address, value discarded: no divergent load
+            v[j] = *reinterpret_cast<const half8_t*>(x + ((img * H + iyc) * W + ixc) * Cin + co[j]);
+            if (!ok) v[j] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2)
+                    acc[c] = __builtin_amdgcn_fdot2((half2_t){v[j][e], v[j][e + 1]}, (half2_t){wr[j][c][e], wr[j][c][e + 1]}, acc[c], false);
+        const float s0 = wave_sum(acc[0]) + b0, s1 = wave_sum(acc[1]) + b1, s2 = wave_sum(acc[2]) + b2, s3 = wave_sum(acc[3]) + b3;
+        if (lane == 0) {
+            const int f = (int)(img % F);
+            const int b = (int)(img / F);
+            const size_t plane = (size_t)F * H * W;
+            half_t* dst = y + (((size_t)b * 4) * F + f) * H * W + (size_t)yh * W + xw;
+            dst[0] = (half_t)s0;
+            dst[plane] = (half_t)s1;
+            dst[2 * plane] = (half_t)s2;
+            dst[3 * plane] = (half_t)s3;
+        }
+    }
+}
+
 int launch_conv_out(const half_t* x, const half_t* wp, const float* bias, half_t* y, int B, int Cin, int F, int H, int W,
                     int Cout, hipStream_t stream) {
     LAVIE_CHECK(Cout <= CONV_OUT_MAXC && Cin % 8 == 0, "conv_out: unsupported Cout=%d Cin=%d", Cout, Cin);
     const size_t lds = (size_t)9 * Cin * Cout * sizeof(half_t);
     LAVIE_CHECK(lds <= 64 * 1024, "conv_out: weights do not fit LDS (%zu B)", lds);
     const long M = (long)B * F * H * W;
+    const int slots = 9 * (Cin / 8);
+    if (Cout == 4 && slots <= 64 * 6) {            // Cin <= 336 (base 320, VSR 256): the register-weight kernel
+        const unsigned grid = (unsigned)((M + 4 * CONV_OUT4_PPW - 1) / (4 * CONV_OUT4_PPW));
+        if (slots <= 64 * 5) hipLaunchKernelGGL(conv_out4_kernel<5>, dim3(grid), dim3(256), 0, stream, x, wp, bias, y, B, Cin, F, H, W);
+        else hipLaunchKernelGGL(conv_out4_kernel<6>, dim3(grid), dim3(256), 0, stream, x, wp, bias, y, B, Cin, F, H, W);
+        LAVIE_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(conv_out_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, stream, x, wp, bias, y, B, Cin, F,
                        H, W, Cout);
     LAVIE_HIP(hipGetLastError());
