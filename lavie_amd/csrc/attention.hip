@@ -345,10 +345,15 @@ __device__ __forceinline__ void att_read_v(unsigned addr, u32x2_t (&lo)[N], u32x
 // one lgkmcnt(0) that the fragments pass THROUGH, so no MFMA that reads them can be scheduled above it
 template <int N, int... DTs>
 __device__ __forceinline__ void att_wait_lds(u32x2_t (&lo)[N], u32x2_t (&hi)[N], std::integer_sequence<int, DTs...>) {
-    if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2])::"memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1])::"memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3])::"memory");
+    else if constexpr (N == 8) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3])::"memory");
+        asm volatile("" : "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7])::"memory");
+    } else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2])::"memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4])::"memory");
     else {
-        static_assert(N == 10, "head dims 40 / 80 / 160");
+        static_assert(N == 10, "head dims 32 / 40 / 64 / 80 / 128 / 160");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4])::"memory");
         asm volatile("" : "+v"(lo[5]), "+v"(hi[5]), "+v"(lo[6]), "+v"(hi[6]), "+v"(lo[7]), "+v"(hi[7]), "+v"(lo[8]), "+v"(hi[8]), "+v"(lo[9]), "+v"(hi[9])::"memory");
     }
@@ -691,6 +696,11 @@ static int dispatch_att(const AttnParams& p, bool big, bool lsum, hipStream_t st
         if (p.dh == 40 && lsum) return big ? launch_att_dma<5, 2, 3, true, SC>(p, stream) : launch_att_dma<5, 1, 3, true, SC>(p, stream);
         if (p.dh == 80) return big ? launch_att_dma<10, 2, 3, false, SC>(p, stream) : launch_att_dma<10, 1, 3, false, SC>(p, stream);
         if (p.dh == 160) return big ? launch_att_dma<20, 2, 2, false, SC>(p, stream) : launch_att_dma<20, 1, 2, false, SC>(p, stream);
+        if constexpr (!SC) {           // the VSR stage's head dims (no sparse-causal attention there)
+            if (p.dh == 32) return big ? launch_att_dma<4, 2, 3, false, false>(p, stream) : launch_att_dma<4, 1, 3, false, false>(p, stream);
+            if (p.dh == 64) return big ? launch_att_dma<8, 2, 3, false, false>(p, stream) : launch_att_dma<8, 1, 3, false, false>(p, stream);
+            if (p.dh == 128) return big ? launch_att_dma<16, 2, 2, false, false>(p, stream) : launch_att_dma<16, 1, 2, false, false>(p, stream);
+        }
     }
     if (p.dh <= 64) {
         if (lsum) {

@@ -235,7 +235,8 @@ def attn_ref(q, k, v, heads, kv_div=1):
     return (p @ vh).permute(0, 2, 1, 3).reshape(nb, lq, c)
 
 
-@pytest.mark.parametrize("nb,l,c", [(3, 160, 1280), (2, 640, 640), (2, 200, 320), (4, 40, 1280), (2, 64, 320), (1, 300, 320)])
+@pytest.mark.parametrize("nb,l,c", [(3, 160, 1280), (2, 640, 640), (2, 200, 320), (4, 40, 1280), (2, 64, 320), (1, 300, 320),
+                                     (2, 300, 256), (2, 200, 512), (1, 330, 1024), (2, 50, 512)])     # head dims 32 / 64 / 128 (VSR)
 def test_self_attention_fused_qkv(ops, nb, l, c):
     g = gen(l + c)
     qkv = q16(torch.randn(nb * l, 3 * c, generator=g))
@@ -260,7 +261,8 @@ def test_self_attention_sharp_softmax(ops):
     assert rel_l2(got, ref) < TOL_OP
 
 
-@pytest.mark.parametrize("b,f,d,c", [(2, 4, 64, 320), (2, 16, 40, 1280), (1, 2, 130, 640)])
+@pytest.mark.parametrize("b,f,d,c", [(2, 4, 64, 320), (2, 16, 40, 1280), (1, 2, 130, 640), (1, 3, 260, 256), (2, 2, 200, 512),
+                                     (1, 4, 70, 1024)])
 def test_cross_attention_text(ops, b, f, d, c):
     """77 text keys shared by the f frames of a video (attention.py:364,529-532)."""
     g = gen(d + c)
