@@ -553,10 +553,15 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
         // ---- online softmax per query column, deferred rescale (as the register-staged kernel)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3]));
-#pragma unroll
-            for (int kt = 1; kt < 4; ++kt)
-                mx = fmaxf(mx, fmaxf(fmaxf(s[kt][qt][0], s[kt][qt][1]), fmaxf(s[kt][qt][2], s[kt][qt][3])));
+            // a chain of three-input maxima (v_max3_f32: 8 slots for the 16 scores; the pairwise tree took 13)
+            float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), s[0][qt][2]);
+            mx = fmaxf(fmaxf(mx, s[0][qt][3]), s[1][qt][0]);
+            mx = fmaxf(fmaxf(mx, s[1][qt][1]), s[1][qt][2]);
+            mx = fmaxf(fmaxf(mx, s[1][qt][3]), s[2][qt][0]);
+            mx = fmaxf(fmaxf(mx, s[2][qt][1]), s[2][qt][2]);
+            mx = fmaxf(fmaxf(mx, s[2][qt][3]), s[3][qt][0]);
+            mx = fmaxf(fmaxf(mx, s[3][qt][1]), s[3][qt][2]);
+            mx = fmaxf(mx, s[3][qt][3]);
             {
                 const unsigned u = __float_as_uint(mx);
                 const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
