@@ -31,7 +31,10 @@ def gen(seed):
 
 # ------------------------------------------------------------------ linear family
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (1280, 960, 320), (154, 640, 768), (384, 1280, 1280),
-                                   (130, 192, 64), (2560, 320, 1280), (77, 128, 128)])
+                                   (130, 192, 64), (2560, 320, 1280), (77, 128, 128),
+                                   # wide GEMMs with a weight matrix beyond 2 MiB: tiles run in 8 x 4 / 16 x 2 blocks, with M-tile
+                                   # counts that are and are not multiples of the block height, and a ragged last M tile
+                                   (2048, 2560, 640), (2450, 2560, 640), (1920, 1920, 1280)])
 def test_linear_bias_residual(ops, M, N, K):
     g = gen(M + N + K)
     a = q16(torch.randn(M, K, generator=g))
@@ -65,7 +68,7 @@ def test_linear_per_batch_bias(ops):
     assert rel_l2(got, ref) < TOL_OP
 
 
-@pytest.mark.parametrize("M,C", [(256, 320), (200, 640)])
+@pytest.mark.parametrize("M,C", [(256, 320), (200, 640), (2720, 640), (1600, 1280)])     # the last two: blocked tile order, ragged blocks
 def test_geglu(ops, M, C):
     g = gen(C)
     a = q16(torch.randn(M, C, generator=g))
