@@ -39,6 +39,9 @@ if ROOT not in sys.path:
 FRAMES, LAT_H, LAT_W, CTX_LEN, CTX_DIM = 16, 40, 64, 77, 768
 DDPM_STEPS, GUIDANCE = 50, 7.5
 UNET_TFLOP = 16.219           # algorithmic TFLOP of one CFG forward at this config
+ATTN2_KV_TFLOP = 0.0945       # of which: the attn2 to_k / to_v projections of the 77 text tokens in the 16 blocks.
+                              # cache_context() runs them ONCE per prompt, not once per step: a video executes
+                              # 50 x (UNET_TFLOP - ATTN2_KV_TFLOP) + ATTN2_KV_TFLOP, and that is what the whole-path rates count
 PEAK_MFMA_TFLOPS = 2500.0     # dense fp16, gfx950 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 CLASS_NAMES = ["conv3x3_igemm", "linear_igemm", "attention", "temporal_attention", "group_norm", "layer_norm", "other",
@@ -136,27 +139,64 @@ def spawn_ranks(n, argv):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh rank processes (one per GPU) with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly as torch.distributed.run would, wait for them, relay rank 0's
     JSON line and return non-zero if any rank failed.  The parent has not touched the GPU (nothing before this point
-    initialises HIP) and never does: the children are ordinary child processes, not an exec of this one."""
+    initialises HIP) and never does: the children are ordinary child processes, not an exec of this one.
+    Every child is polled: as soon as one exits non-zero the others are terminated (a rank that dies early would
+    otherwise leave the rest in rendezvous or a collective until the backend's timeout), and they are terminated too
+    if the parent is interrupted."""
     import subprocess
+    import threading
     port = _free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in out0.splitlines():                 # the contract is ONE JSON line on stdout: library chatter (gloo prints
+    lines0 = []
+
+    def drain(pipe):                               # rank 0's stdout, read continuously so that the child never blocks on it
+        for line in pipe:
+            lines0.append(line)
+
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        reader = threading.Thread(target=drain, args=(procs[0].stdout,), daemon=True)
+        reader.start()
+        failed = False
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                failed = True
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.5)
+        if failed:
+            time.sleep(1.0)                        # ranks failing together (bad flag, no GPU) report their own codes
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        reader.join(timeout=10)
+    finally:
+        for p in procs:                            # interrupted parent / unexpected error: leave no rank behind
+            if p.poll() is None:
+                p.kill()
+    codes = [p.returncode for p in procs]
+    for line in lines0:                            # the contract is ONE JSON line on stdout: library chatter (gloo prints
         if line.lstrip().startswith("{"):          # its rendezvous banner to stdout) goes to stderr
-            sys.stdout.write(line + "\n")
+            sys.stdout.write(line if line.endswith("\n") else line + "\n")
         elif line.strip():
-            sys.stderr.write(line + "\n")
+            sys.stderr.write(line if line.endswith("\n") else line + "\n")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
-        sys.stderr.write(f"bench.py: rank(s) failed: {bad}\n")
+        sys.stderr.write(f"bench.py: rank(s) failed (rank, exit code; negative = terminated after another rank failed): {bad}\n")
         return 1
     return 0
 
@@ -166,6 +206,8 @@ def launcher_selftest(rank, world, args):
     weight broadcast, per-rank work, latent all_gather, barrier, MAX-over-ranks timing, one JSON line from rank 0 — around
     a stand-in for the denoiser.  Its line is labelled as such and carries no metric."""
     from lavie_amd import prompt_dp
+    if os.environ.get("LAVIE_BENCH_SELFTEST_FAIL_RANK") == str(rank):     # test hook: this rank dies before the rendezvous
+        return 3
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
@@ -206,6 +248,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the UNet forward from a hipGraph (A/B switch; implies --no-profile: events cannot be captured)")
     ap.add_argument("--ddpm-steps", type=int, default=DDPM_STEPS, help=argparse.SUPPRESS)   # debugging only
+    ap.add_argument("--prompts-per-forward", type=int, default=4,
+                    help="after the headline (single-prompt) measurement, also time k prompts batched into ONE UNet forward "
+                         "(batch 2k; SURVEY §8e 'batched B = 2k if memory-profitable'; BASELINE.json configs[2] readiness) and "
+                         "report it as the extra object `batched`; 1 = skip")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -296,7 +342,36 @@ def main():
         elapsed = float(tt.item())
     finite = all(bool(torch.isfinite(g).all()) for g in gathered)
 
+    # ---- extra: k prompts per UNet forward (batch 2k), what a rank of configs[2] (8 prompts per GPU) would run.  Separate
+    # from the headline: the metric's configuration is ONE prompt at a time (configs[1]).
+    batched = None
+    kpf = max(1, min(args.prompts_per_forward, 4))              # the engine takes UNet batches up to 8
+    if kpf > 1:
+        def one_batch(base):
+            sets = [synth_inputs(rank + world * (base + j), device) for j in range(kpf)]
+            gens = [torch.Generator().manual_seed(3000 + rank + world * (base + j)) for j in range(kpf)]
+            return pipe(prompt_embeds=torch.cat([s_[0] for s_ in sets]), negative_prompt_embeds=torch.cat([s_[1] for s_ in sets]),
+                        latents=torch.cat([s_[2] for s_ in sets]), height=LAT_H * 8, width=LAT_W * 8, video_length=FRAMES,
+                        num_inference_steps=args.ddpm_steps, guidance_scale=GUIDANCE, generator=gens, output_type="latent").video
+        nb = max(1, (args.steps + kpf - 1) // kpf)
+        one_batch(0)                                             # untimed: workspace growth + warm-up at the batched shape
+        barrier()
+        tb = time.perf_counter()
+        bouts = [one_batch(1000 + i * kpf) for i in range(nb)]
+        barrier()
+        bel = time.perf_counter() - tb
+        if world > 1:
+            tt = torch.tensor([bel], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            bel = float(tt.item())
+        batched = {"k": kpf, "unet_batch": 2 * kpf, "batches": nb, "value": nb * kpf * world / bel, "unit": "video-latents/s",
+                   "ms_per_video": 1e3 * bel / (nb * kpf), "outputs_finite": all(bool(torch.isfinite(o).all()) for o in bouts),
+                   "note": "k prompts share one UNet forward (reference loops prompts one at a time, sample.py:78-91); "
+                           "not the headline configuration"}
+        net.prepare(2, FRAMES, LAT_H, LAT_W, CTX_LEN)
+
     total_videos = args.steps * world
+    video_tflop = (UNET_TFLOP - ATTN2_KV_TFLOP) * args.ddpm_steps + ATTN2_KV_TFLOP      # text K/V once per prompt
     result = {
         "metric": "video-latents/sec (16f x 320x512, 50 DDPM steps)",
         "value": total_videos / elapsed,
@@ -313,10 +388,17 @@ def main():
         "outputs_finite": finite,
         "hip_graph": bool(args.graph),
         "setup_seconds": setup_s,
-        "achieved_tflops_whole_path": UNET_TFLOP * args.ddpm_steps * total_videos / elapsed / world,
-        "mfma_fraction_whole_path": UNET_TFLOP * args.ddpm_steps * total_videos / elapsed / world / PEAK_MFMA_TFLOPS,
+        "achieved_tflops_whole_path": video_tflop * total_videos / elapsed / world,
+        "mfma_fraction_whole_path": video_tflop * total_videos / elapsed / world / PEAK_MFMA_TFLOPS,
+        "tflop_per_video_executed": video_tflop,
+        "ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none (single process)",
     }
+    if batched is not None:
+        batched["vs_single_prompt"] = batched["value"] / result["value"]
+        result["batched"] = batched
 
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # filled from rocprofv3 --pmc passes, see DESIGN.md
     if rank == 0 and timed is not None:
         temp, conv = timed[3], timed[7]
         if conv["launches"]:
@@ -334,7 +416,6 @@ def main():
                                            "traffic": None, "launches": temp["launches"],
                                            "avg_launch_us": 1e3 * temp["ms"] / temp["launches"],
                                            "bytes_per_launch": temp["bytes"] / temp["launches"]}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # filled from rocprofv3 --pmc passes, see DESIGN.md
         if os.path.isfile(pmc):
             tr = json.load(open(pmc))
             for key in ("roofline", "roofline_temporal"):
@@ -361,7 +442,15 @@ def main():
                 a = row["flops"] / (row["ms"] * 1e-3) / 1e12
                 result[key] = {"kernels": kernels, "source": "one instrumented UNet forward after the timed region", "bound": "mfma",
                                "achieved": a, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": a / PEAK_MFMA_TFLOPS,
-                               "launches": row["launches"], "avg_launch_us": 1e3 * row["ms"] / row["launches"]}
+                               "launches": row["launches"], "avg_launch_us": 1e3 * row["ms"] / row["launches"],
+                               # the second roof: every operand element once (A, W, C [+ R]) / time against 8 TB/s.  The
+                               # short-K (K = 320 / 640) half of the linear class is bound by this one, not by MFMA
+                               "algorithmic_gbytes": row["bytes"] / 1e9,
+                               "hbm_achieved_gbs": row["bytes"] / (row["ms"] * 1e-3) / 1e9,
+                               "hbm_frac": row["bytes"] / (row["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                pk = {"roofline_linear_class": "linear", "roofline_conv_class": "conv_class"}[key]
+                if os.path.isfile(pmc) and pk in json.load(open(pmc)):      # HBM bytes per launch, committed rocprofv3 --pmc passes
+                    result[key]["traffic"] = json.load(open(pmc))[pk]
         result["kernel_breakdown"] = {
             "unet_forward_ms_instrumented": fwd_ms,
             "classes": [dict(name=r["name"], launches=r["launches"], ms=round(r["ms"], 4),

@@ -223,11 +223,13 @@ int lavie_latents_to_scaled_model_input(const float* x, void* model_in2, long lo
     return launch_f32_to_f16_dup2(x, H(model_in2), n, input_scale, S(stream));
 }
 
-int lavie_debug_force_tile(int mode) { igemm_force_tile(mode); return 0; }
-int lavie_debug_force_splits(int s) { igemm_force_splits(s); return 0; }
-int lavie_debug_conv_tap_major(int on) { g_tap_major = on; return 0; }
-int lavie_debug_attention_qt(int qt) { attention_force_qt(qt); return 0; }
-int lavie_debug_temporal_budget(int bytes) { temporal_set_budget(bytes); return 0; }
+// Every switch below changes which kernels a forward enqueues: each bumps the process-wide debug epoch, which is part of
+// the captured graph's key (engine.h GraphKey::debug_epoch), so a replay never runs a selection made under other switches.
+int lavie_debug_force_tile(int mode) { bump_debug_epoch(); igemm_force_tile(mode); return 0; }
+int lavie_debug_force_splits(int s) { bump_debug_epoch(); igemm_force_splits(s); return 0; }
+int lavie_debug_conv_tap_major(int on) { bump_debug_epoch(); g_tap_major = on; return 0; }
+int lavie_debug_attention_qt(int qt) { bump_debug_epoch(); attention_force_qt(qt); return 0; }
+int lavie_debug_temporal_budget(int bytes) { bump_debug_epoch(); temporal_set_budget(bytes); return 0; }
 int lavie_debug_ppx_stamps(unsigned long long* out256) {
     LAVIE_CHECK(out256, "ppx_stamps: null output");
     return igemm_ppx_read_stamps(out256);

@@ -18,6 +18,9 @@ namespace lavie {
 // Thread-local error text for lavie_last_error().
 void set_error(const char* fmt, ...);
 const char* get_error();
+// kernel-selection debug switches (lavie_debug_*): a process-wide epoch the captured-graph key includes
+void bump_debug_epoch();
+unsigned long debug_epoch();
 
 #define LAVIE_CHECK(cond, ...)                 \
     do {                                       \

@@ -21,6 +21,10 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+static unsigned long g_debug_epoch = 0;
+void bump_debug_epoch() { ++g_debug_epoch; }
+unsigned long debug_epoch() { return g_debug_epoch; }
+
 #define RUN(expr)                 \
     do {                          \
         int rc_ = (expr);         \
@@ -78,6 +82,7 @@ UNet::UNet(const lavie_unet_config& cfg) : cfg_(cfg) { build_param_list(); }
 UNet::~UNet() {
     drop_graph();
     if (cap_stream_) (void)hipStreamDestroy(cap_stream_);
+    if (kv_block_) (void)hipFree(kv_block_);
 }
 
 int UNet::validate_config() {
@@ -1068,7 +1073,7 @@ int UNet::forward_graph(const half_t* sample, const float* timesteps, const half
     for (int cls = 0; cls < KC_COUNT; ++cls) profiling = profiling || profile_enabled(cls);
     GraphKey key;
     key.sample = sample; key.t = timesteps; key.ctx = ctx; key.out = out; key.kv_ctx = kv_ctx_;
-    key.B = B; key.F = F; key.H = H; key.W = W; key.L = ctx_len; key.gen = graph_gen_; key.stream = stream;
+    key.B = B; key.F = F; key.H = H; key.W = W; key.L = ctx_len; key.gen = graph_gen_; key.debug_epoch = debug_epoch(); key.stream = stream;
     if (profiling) return forward(sample, timesteps, ctx, out, B, F, H, W, ctx_len, stream, nullptr);
     if (graph_exec_ && key == graph_key_) {
         LAVIE_HIP(hipGraphLaunch(graph_exec_, stream));
@@ -1122,12 +1127,25 @@ int UNet::cache_context(const half_t* ctx, int B, int ctx_len, hipStream_t strea
     LAVIE_CHECK(ws_.total_bytes() > 0, "cache_context: call lavie_unet_prepare first (split-K slabs come from the workspace)");
     const size_t rows = (size_t)B * ctx_len;
     const int X = cfg_.cross_attention_dim;
-    if (rows > kv_cache_rows_ || kv2_cache_.size() != transformers_.size()) {      // grow-only, from the weights arena
+    if (rows > kv_cache_rows_ || kv2_cache_.size() != transformers_.size()) {
+        // the cache lives in a block of its own: a longer context frees the old block instead of stranding it in the
+        // grow-only weights arena.  Earlier forwards that read the old block are ordered before the free by the sync.
+        size_t total = 0;
+        auto span = [&](size_t i) { return (rows * 2 * transformers_[i].C * sizeof(half_t) + 255) & ~(size_t)255; };
+        for (size_t i = 0; i < transformers_.size(); ++i) total += span(i) * (transformers_[i].attn1_cross ? 2 : 1);
+        if (kv_block_) {
+            LAVIE_HIP(hipStreamSynchronize(stream));
+            LAVIE_HIP(hipFree(kv_block_));
+            kv_block_ = nullptr;
+            kv_cache_rows_ = 0;
+        }
+        LAVIE_HIP(hipMalloc(&kv_block_, total));
         kv2_cache_.assign(transformers_.size(), nullptr);
         kv1_cache_.assign(transformers_.size(), nullptr);
+        char* cur = (char*)kv_block_;
         for (size_t i = 0; i < transformers_.size(); ++i) {
-            WALLOC(kv2_cache_[i], half_t, rows * 2 * transformers_[i].C);
-            if (transformers_[i].attn1_cross) WALLOC(kv1_cache_[i], half_t, rows * 2 * transformers_[i].C);
+            kv2_cache_[i] = (half_t*)cur; cur += span(i);
+            if (transformers_[i].attn1_cross) { kv1_cache_[i] = (half_t*)cur; cur += span(i); }
         }
         kv_cache_rows_ = rows;
     }

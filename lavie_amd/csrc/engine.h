@@ -149,10 +149,11 @@ private:
         const void *sample = nullptr, *t = nullptr, *ctx = nullptr, *out = nullptr, *kv_ctx = nullptr;
         int B = 0, F = 0, H = 0, W = 0, L = 0;
         unsigned long gen = 0;          // bumped by everything that changes what a forward enqueues (workspace, caches, modes)
+        unsigned long debug_epoch = 0;  // process-wide: bumped by every lavie_debug_* kernel-selection switch (api.cpp)
         hipStream_t stream = nullptr;
         bool operator==(const GraphKey& o) const {
             return sample == o.sample && t == o.t && ctx == o.ctx && out == o.out && kv_ctx == o.kv_ctx && B == o.B && F == o.F &&
-                   H == o.H && W == o.W && L == o.L && gen == o.gen && stream == o.stream;
+                   H == o.H && W == o.W && L == o.L && gen == o.gen && debug_epoch == o.debug_epoch && stream == o.stream;
         }
     };
     void drop_graph();
@@ -191,6 +192,7 @@ private:
     // cached text K/V (cache_context): one [B * ctx_len, 2C] buffer per transformer (attn2; attn1 on VSR cross levels)
     std::vector<half_t*> kv2_cache_, kv1_cache_;
     size_t kv_cache_rows_ = 0;                      // rows the buffers were allocated for
+    void* kv_block_ = nullptr;                      // ONE hipMalloc'd block behind every K/V cache buffer: freed and reallocated on growth
     const half_t* kv_ctx_ = nullptr;
     int kv_B_ = 0, kv_len_ = 0;
     // spatial size of the running call (set by prepare()/forward() before run())

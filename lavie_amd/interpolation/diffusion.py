@@ -163,16 +163,18 @@ class SpacedDiffusion:
         noise_dev = torch.empty_like(x)
         steps = list(range(self.num_timesteps))[::-1]
         t_dev = torch.tensor([float(self.timestep_map[i]) for i in steps], dtype=torch.float32, device=dev)
-        for j, i in enumerate(steps):
-            if max_steps is not None and j >= max_steps:
-                break
-            if use_concat:
-                inp[:, : x.shape[1]].copy_(model_in)                          # th.concat([x, x_start], dim=1), :285
-            eps = unet(inp, t_dev[j], encoder_hidden_states=ctx).sample
-            coeffs = self.ddim_coefficients(i, eta)
-            step_noise = noise_dev.normal_() if coeffs[4] != 0.0 else None
-            ops.cfg_ddpm_step(eps, x, step_noise, model_in, cfg_scale, coeffs)
-        unet.cache_context(None)
+        try:                                     # an exception in the loop must not leave the engine holding ctx
+            for j, i in enumerate(steps):
+                if max_steps is not None and j >= max_steps:
+                    break
+                if use_concat:
+                    inp[:, : x.shape[1]].copy_(model_in)                          # th.concat([x, x_start], dim=1), :285
+                eps = unet(inp, t_dev[j], encoder_hidden_states=ctx).sample
+                coeffs = self.ddim_coefficients(i, eta)
+                step_noise = noise_dev.normal_() if coeffs[4] != 0.0 else None
+                ops.cfg_ddpm_step(eps, x, step_noise, model_in, cfg_scale, coeffs)
+        finally:
+            unet.cache_context(None)
         return torch.cat([x, x], dim=0)
 
 

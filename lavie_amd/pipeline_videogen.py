@@ -164,46 +164,48 @@ class VideoGenPipeline:
         main = torch.cuda.current_stream(dev)
         t_dev = torch.tensor(timesteps, dtype=torch.float32, device=dev)
 
-        for i, t in enumerate(timesteps):
-            eps = self.unet(model_in, t_dev[i], encoder_hidden_states=ctx).sample      # line 670
-            coeffs = sch.coefficients(t, eta) if takes_eta else sch.coefficients(t)
-            noise = None
-            slot = i & 1
-            if coeffs[4] != 0.0:            # the step adds noise (DDPM: every step but the last; DDIM: only with eta > 0)
-                if host_noise:
-                    if copy_done[slot] is not None:
-                        copy_done[slot].synchronize()
-                    if isinstance(generator, list):
+        try:                                     # an exception in a callback or kernel must not leave the engine holding ctx
+            for i, t in enumerate(timesteps):
+                eps = self.unet(model_in, t_dev[i], encoder_hidden_states=ctx).sample      # line 670
+                coeffs = sch.coefficients(t, eta) if takes_eta else sch.coefficients(t)
+                noise = None
+                slot = i & 1
+                if coeffs[4] != 0.0:            # the step adds noise (DDPM: every step but the last; DDIM: only with eta > 0)
+                    if host_noise:
+                        if copy_done[slot] is not None:
+                            copy_done[slot].synchronize()
+                        if isinstance(generator, list):
+                            for j, g in enumerate(gens):
+                                torch.randn(x.shape[1:], generator=g, dtype=torch.float32, out=pinned[slot][j])
+                        else:
+                            torch.randn(x.shape, generator=generator, dtype=torch.float32, out=pinned[slot])
+                        if step_done[slot] is not None:
+                            self._copy_stream.wait_event(step_done[slot])
+                        with torch.cuda.stream(self._copy_stream):
+                            staged[slot].copy_(pinned[slot], non_blocking=True)
+                        copy_done[slot] = torch.cuda.Event()
+                        copy_done[slot].record(self._copy_stream)
+                        main.wait_event(copy_done[slot])
+                        noise = staged[slot]
+                    elif isinstance(generator, list):
                         for j, g in enumerate(gens):
-                            torch.randn(x.shape[1:], generator=g, dtype=torch.float32, out=pinned[slot][j])
+                            noise_dev[j].normal_(generator=g)
+                        noise = noise_dev
                     else:
-                        torch.randn(x.shape, generator=generator, dtype=torch.float32, out=pinned[slot])
-                    if step_done[slot] is not None:
-                        self._copy_stream.wait_event(step_done[slot])
-                    with torch.cuda.stream(self._copy_stream):
-                        staged[slot].copy_(pinned[slot], non_blocking=True)
-                    copy_done[slot] = torch.cuda.Event()
-                    copy_done[slot].record(self._copy_stream)
-                    main.wait_event(copy_done[slot])
-                    noise = staged[slot]
-                elif isinstance(generator, list):
-                    for j, g in enumerate(gens):
-                        noise_dev[j].normal_(generator=g)
-                    noise = noise_dev
+                        noise = noise_dev.normal_(generator=generator) if generator is not None else noise_dev.normal_()
+                next_scale = in_scale(timesteps[i + 1]) if in_scale and i + 1 < len(timesteps) else 1.0
+                if do_cfg:
+                    ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs, next_scale)   # lines 667, 679-683 fused
                 else:
-                    noise = noise_dev.normal_(generator=generator) if generator is not None else noise_dev.normal_()
-            next_scale = in_scale(timesteps[i + 1]) if in_scale and i + 1 < len(timesteps) else 1.0
-            if do_cfg:
-                ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs, next_scale)   # lines 667, 679-683 fused
-            else:
-                ops.sampler_step(eps, x, noise, model_in, coeffs, next_scale)                    # lines 667, 683
-            if host_noise and coeffs[4] != 0.0:
-                step_done[slot] = torch.cuda.Event()
-                step_done[slot].record(main)
-            if callback is not None and i % callback_steps == 0:
-                callback(i, t, x)
-        if hasattr(self.unet, "cache_context"):
-            self.unet.cache_context(None)
+                    ops.sampler_step(eps, x, noise, model_in, coeffs, next_scale)                    # lines 667, 683
+                if host_noise and coeffs[4] != 0.0:
+                    step_done[slot] = torch.cuda.Event()
+                    step_done[slot].record(main)
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, x)
+        finally:
+            if hasattr(self.unet, "cache_context"):
+                self.unet.cache_context(None)
         return x
 
     @torch.no_grad()

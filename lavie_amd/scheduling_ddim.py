@@ -63,6 +63,29 @@ class DDIMScheduler:
                                       steps_offset=steps_offset, prediction_type=prediction_type, thresholding=thresholding,
                                       timestep_spacing=timestep_spacing)
 
+
+    _CONFIG_KEYS = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "clip_sample", "set_alpha_to_one",
+                    "steps_offset", "prediction_type", "thresholding", "timestep_spacing")
+
+    @classmethod
+    def from_config(cls, config, **overrides):
+        """Builds the scheduler from the fields of a diffusers `scheduler_config.json` (a dict or a path to the file), as
+        `DDIMScheduler.from_config(pipeline.scheduler.config, beta_schedule=...)` does at vsr/sample.py:49-53 and
+        base/pipelines/sample.py:45-49.  Keys this class does not model (`_class_name`, `trained_betas`, ...) are ignored;
+        `overrides` win over the file.  The VSR stage's scheduler comes from the x4-upscaler checkpoint's
+        scheduler/scheduler_config.json, which is NOT in the reference tree: its `prediction_type`, betas and
+        `steps_offset` must be taken from the user's file — the constructor defaults (epsilon, SD-1.4 betas) are not a
+        statement about what the reference's VSR stage runs (parity unpinned for that configuration)."""
+        if isinstance(config, (str, bytes)) or hasattr(config, "__fspath__"):
+            import json
+            with open(config) as fh:
+                config = json.load(fh)
+        cfg = {k: config[k] for k in cls._CONFIG_KEYS if k in config}
+        cfg.update(overrides)
+        unknown = set(overrides) - set(cls._CONFIG_KEYS)
+        if unknown:
+            raise TypeError(f"from_config: unknown scheduler fields {sorted(unknown)}")
+        return cls(**cfg)
     def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:    # :184-196
         return sample
 

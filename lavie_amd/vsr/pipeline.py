@@ -90,17 +90,19 @@ class VideoUpscalePipeline:
         t_dev = torch.tensor(timesteps, dtype=torch.float32, device=dev)
         self.unet.prepare(2 * p, x.shape[2], x.shape[3], x.shape[4], ctx.shape[1])
         ctx = self.unet.cache_context(ctx)       # text keys / values once per chunk, not once per block and step
-        for i, t in enumerate(timesteps):
-            eps = self.unet(model_in, t_dev[i], low, encoder_hidden_states=ctx, class_labels=labels).sample        # :716-718
-            coeffs = sch.coefficients(t, eta) if takes_eta else sch.coefficients(t)
-            noise = None
-            if coeffs[4] != 0.0:
-                noise = noise_dev.copy_(randn_tensor(x.shape, generator=generator, device=dev, dtype=torch.float32))
-            next_scale = in_scale(timesteps[i + 1]) if in_scale and i + 1 < len(timesteps) else 1.0
-            ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs, next_scale)                          # :721-726
-            if callback is not None and i % callback_steps == 0:
-                callback(i, t, x)
-        self.unet.cache_context(None)
+        try:                                     # an exception in a callback or kernel must not leave the engine holding ctx
+            for i, t in enumerate(timesteps):
+                eps = self.unet(model_in, t_dev[i], low, encoder_hidden_states=ctx, class_labels=labels).sample        # :716-718
+                coeffs = sch.coefficients(t, eta) if takes_eta else sch.coefficients(t)
+                noise = None
+                if coeffs[4] != 0.0:
+                    noise = noise_dev.copy_(randn_tensor(x.shape, generator=generator, device=dev, dtype=torch.float32))
+                next_scale = in_scale(timesteps[i + 1]) if in_scale and i + 1 < len(timesteps) else 1.0
+                ops.cfg_ddpm_step(eps, x, noise, model_in, guidance_scale, coeffs, next_scale)                          # :721-726
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, x)
+        finally:
+            self.unet.cache_context(None)
         return x
 
     @torch.no_grad()

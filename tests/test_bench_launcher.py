@@ -44,3 +44,14 @@ def test_failing_rank_propagates():
         pytest.skip("needs a box without a GPU")
     r = run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0 and "rank(s) failed" in r.stderr
+
+
+def test_one_rank_dying_early_ends_the_job_promptly():
+    """Rank 1 exits before the rendezvous; rank 0 would sit in init_process_group until the backend's timeout.  The
+    parent polls every child, terminates the survivor and reports which rank failed — within seconds."""
+    import time
+    t0 = time.perf_counter()
+    r = run(["--gpus", "2", "--steps", "1", "--selftest-launcher"], {"LAVIE_BENCH_SELFTEST_FAIL_RANK": "1"})
+    took = time.perf_counter() - t0
+    assert r.returncode != 0 and "rank(s) failed" in r.stderr and "(1, 3)" in r.stderr
+    assert took < 120, took

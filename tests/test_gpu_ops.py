@@ -10,15 +10,17 @@ from gpu_util import TOL_OP, f32, h16, q16, rel_l2, rows, unrows
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "row128-tiles", "split-k-3", "pingpong", "pingpong-split-k-2"])
+@pytest.fixture(scope="module", params=["auto", "row128-tiles", "split-k-3", "pingpong", "pingpong-split-k-2", "ppx-persistent"])
 def ops(request):
-    """Every operator test runs five times: automatic choices, the 128-row GEMM kernel forced (widest tile),
-    split-K = 3 forced (fp32 slabs + fixed-order reduce) on every implicit GEMM that has >= 3 K-tiles, and the
-    160x320 two-group ping-pong kernel forced (every GEMM with N % 320 == 0), alone and with split-K = 2."""
+    """Every operator test runs six times: automatic choices, the 128-row GEMM kernel forced (widest tile),
+    split-K = 3 forced (fp32 slabs + fixed-order reduce) on every implicit GEMM that has >= 3 K-tiles, the
+    160x320 two-group ping-pong kernel forced (every GEMM with N % 320 == 0), alone and with split-K = 2, and the
+    persistent ping-pong kernel (igemm_ppx.hip, mode 7) forced on every plain GEMM whose shape it takes
+    (M % 160 == 0, >= 5 K-tiles, N % 320 == 0 or N % 256 == 0)."""
     assert torch.cuda.is_available(), "gpu tests need a HIP device"
     from lavie_amd import _lib, ops as o
     lib = _lib.load()
-    lib.lavie_debug_force_tile({"row128-tiles": 1, "pingpong": 3, "pingpong-split-k-2": 3}.get(request.param, 0))
+    lib.lavie_debug_force_tile({"row128-tiles": 1, "pingpong": 3, "pingpong-split-k-2": 3, "ppx-persistent": 7}.get(request.param, 0))
     lib.lavie_debug_force_splits({"split-k-3": 3, "pingpong-split-k-2": 2}.get(request.param, 0))
     yield o
     lib.lavie_debug_force_tile(0)
@@ -34,7 +36,12 @@ def gen(seed):
                                    (130, 192, 64), (2560, 320, 1280), (77, 128, 128),
                                    # wide GEMMs with a weight matrix beyond 2 MiB: tiles run in 8 x 4 / 16 x 2 blocks, with M-tile
                                    # counts that are and are not multiples of the block height, and a ragged last M tile
-                                   (2048, 2560, 640), (2450, 2560, 640), (1920, 1920, 1280)])
+                                   (2048, 2560, 640), (2450, 2560, 640), (1920, 1920, 1280),
+                                   # shapes the AUTOMATIC rule sends to the persistent ping-pong kernel (>= 256 tiles of 160x320,
+                                   # 5..10 K-tiles): the L0 / L1 to_out + residual GEMMs of the bench shape, and a ragged tile count
+                                   (40960, 320, 320), (20480, 640, 640), (41120, 320, 320),
+                                   # persistent kernel only when forced (mode 7): 160-row multiples with few tiles, N % 256 == 0
+                                   (1600, 960, 320), (2560, 512, 640)])
 def test_linear_bias_residual(ops, M, N, K):
     g = gen(M + N + K)
     a = q16(torch.randn(M, K, generator=g))

@@ -277,3 +277,23 @@ def test_vsr_low_res_noise_schedule_and_add_noise():
     for level in (0, 20, 350):
         got = sch.add_noise(img, noise, torch.tensor([level, level]))
         assert torch.allclose(got, add_low_res_noise(img, noise, level), rtol=1e-4, atol=1e-5)
+
+
+def test_ddim_from_config_takes_the_callers_scheduler_config(tmp_path):
+    """vsr/sample.py:49-53 builds its DDIM scheduler from the checkpoint's scheduler_config.json (absent from the reference
+    tree): `from_config` takes those fields from a dict or a file instead of implying the epsilon / SD-1.4 defaults."""
+    import json
+    from lavie_amd.scheduling_ddim import DDIMScheduler
+    cfg = {"_class_name": "DDIMScheduler", "_diffusers_version": "0.8.0", "beta_start": 0.0001, "beta_end": 0.02,
+           "beta_schedule": "scaled_linear", "clip_sample": False, "num_train_timesteps": 1000, "prediction_type": "v_prediction",
+           "set_alpha_to_one": False, "steps_offset": 1, "trained_betas": None}
+    path = tmp_path / "scheduler_config.json"
+    path.write_text(json.dumps(cfg))
+    for src in (cfg, str(path)):
+        s = DDIMScheduler.from_config(src, beta_schedule="linear")
+        assert s.config.prediction_type == "v_prediction" and s.config.beta_schedule == "linear" and s.config.steps_offset == 1
+    ref = DDIMScheduler(beta_schedule="scaled_linear", prediction_type="v_prediction")
+    got = DDIMScheduler.from_config(cfg)
+    assert torch.equal(ref.alphas_cumprod, got.alphas_cumprod)
+    with pytest.raises(TypeError):
+        DDIMScheduler.from_config(cfg, no_such_field=1)

@@ -259,3 +259,37 @@ def test_vsr_unet_small_matches_reference():
     got = V.vsr_unet_forward(sd, x, lr, 500, ctx, labels, block_out_channels=(64, 128), attn_levels=(False, True),
                              only_cross_attention=(True, False), layers_per_block=1, heads=4)
     assert rel_l2(got, ref) < 1e-5
+
+
+# ------------------------------------------------------------------ a5 / a17: pins against reference-HELD text
+@pytest.mark.parametrize("dim", [320, 640])
+def test_geglu_ff_matches_reference_held_feedforward(dim):
+    """a17: oracle.geglu_ff against the FeedForward / GEGLU classes the reference itself holds
+    (vsr/models/diffusers_attention.py:734-822, diffusers' text vendored by the reference; the class the base model takes
+    from the absent diffusers package at attention.py:17,479 under the same name and state-dict keys)."""
+    m = refimport.load_vsr_blocks()
+    ff = m.diffusers_attention.FeedForward(dim, dropout=0.0, activation_fn="geglu").eval()
+    assert sorted(ff.state_dict()) == ["net.0.proj.bias", "net.0.proj.weight", "net.2.bias", "net.2.weight"]
+    assert tuple(ff.net[0].proj.weight.shape) == (8 * dim, dim) and tuple(ff.net[2].weight.shape) == (dim, 4 * dim)
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in ff.state_dict().items()}, 21)
+    ff.load_state_dict(sd)
+    x = torch.randn(3, 50, dim, generator=torch.Generator().manual_seed(dim)) * 2.0
+    with torch.no_grad():
+        ref = ff(x)
+    assert rel_l2(O.geglu_ff(sd, "", x), ref) < 1e-6
+
+
+def test_timestep_sinusoid_matches_reference_held_embedding():
+    """a5: the oracle's Timesteps(320, flip_sin_to_cos=True, freq_shift=0) against the sinusoidal embedding the reference
+    holds in-tree (base/models/utils.py:74-94: [cos | sin], w_k = max_period^(-k/half)), every DDPM timestep the 50-step
+    schedule visits plus fractional ones (Euler)."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("ref_base_utils", "/root/reference/base/models/utils.py")
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    t = torch.cat([torch.arange(980, -1, -20, dtype=torch.float32), torch.tensor([999.0, 0.5, 123.456, 1.0])])
+    for dim in (320, 256):
+        ref = mod.timestep_embedding(t, dim)
+        got = O.timestep_sinusoid(t, dim)
+        assert got.shape == ref.shape == (t.numel(), dim)
+        assert torch.equal(got, ref) or (got - ref).abs().max().item() < 1e-6
