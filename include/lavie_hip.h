@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAVIE_ABI_VERSION 4
+#define LAVIE_ABI_VERSION 5
 #define LAVIE_MAX_LEVELS 8
 
 const char* lavie_last_error(void);
@@ -75,6 +75,36 @@ int lavie_temporal_conv_f16(const void* x, int C, const void* Wp, const float* b
 int lavie_pack_temporal_conv_f16(const void* w, void* out, int Cout, int Cin, int taps, void* stream);
 /* GEGLU projection [2*inner, K] (+ bias) -> 16-row value/gate interleave expected by lavie_linear_f16(geglu=1). */
 int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float* bias_out, int N, int K, void* stream);
+
+/* Fused feed-forward sub-block (ABI 5): y = x + W2 (h * gelu(g)) + b2 with (h, g) = W1 LayerNorm(x) + b1 — the
+ * `hidden_states = self.ff(self.norm3(hidden_states)) + hidden_states` line of BasicTransformerBlock
+ * (/root/reference/base/models/attention.py:558; FeedForward / GEGLU spec /root/reference/vsr/models/diffusers_attention.py:
+ * 734-822) as ONE kernel: the [M, 4C] GEGLU intermediate never exists in memory.  Rows stay in registers from load to store,
+ * weights stream through LDS in a packed image (lavie_pack_geglu_mlp_f16).  y may alias x.  Built for C = 320:
+ * lavie_geglu_mlp_image_bytes returns 0 for a width the kernel is not built for.
+ *   w1 [8C, C] = ff.net.0.proj.weight (value rows, then gate rows), b1 [8C] fp16, w2 [C, 4C] = ff.net.2.weight (fp16 device);
+ *   img: lavie_geglu_mlp_image_bytes(C) bytes, b1img: lavie_geglu_mlp_bias_floats(C) floats (device, written by the pack call);
+ *   gamma / beta: norm3 weight / bias fp32 [C]; b2: ff.net.2.bias fp32 [C]. */
+long long lavie_geglu_mlp_image_bytes(int C);
+long long lavie_geglu_mlp_bias_floats(int C);
+int lavie_pack_geglu_mlp_f16(const void* w1, const void* b1_f16, const void* w2, int C, void* img, float* b1img, void* stream);
+int lavie_geglu_mlp_f16(const void* x, void* y, int M, int C, const void* img, const float* b1img, const float* gamma,
+                        const float* beta, const float* b2, float eps, void* stream);
+
+/* Fused temporal sub-block (ABI 5): y = x + to_out(attn_temp(norm_temp(x))) — lines 548-555 of BasicTransformerBlock.forward
+ * with TemporalAttention.forward / _attention (/root/reference/base/models/attention.py:580-667) as ONE kernel on token rows in
+ * (b f) d order: LayerNorm, the q / k / v projections, scale + rotary, relative-position bias, softmax over the frames of a
+ * pixel, P V, to_out + bias + residual.  Neither q|k|v nor the attention output exists in memory; the two rearranges of the
+ * reference are row addressing.  y may alias x.  Built for C = 320, 8 heads, exactly 16 frames, rotary over 32 channels:
+ * lavie_temporal_block_image_bytes returns 0 otherwise.
+ *   wq / wk / wv / wo: attn_temp.to_q / to_k / to_v / to_out.0 weights [C, C] fp16 (device); img: image bytes (device);
+ *   gamma / beta: norm_temp fp32 [C]; bo: to_out.0.bias fp32 [C]; relbias fp32 [heads, F, F] (query, key);
+ *   rot_cos / rot_sin fp32 [F, rot_dim / 2]; scale = dim_head^-0.5 (applied to q before the rotary embedding, :640). */
+long long lavie_temporal_block_image_bytes(int C, int heads, int F, int rot_dim);
+int lavie_pack_temporal_block_f16(const void* wq, const void* wk, const void* wv, const void* wo, int C, void* img, void* stream);
+int lavie_temporal_block_f16(const void* x, void* y, int B, int F, int D, int C, int heads, const void* img, const float* gamma,
+                             const float* beta, const float* bo, const float* relbias, const float* rot_cos,
+                             const float* rot_sin, int rot_dim, float scale, float eps, void* stream);
 
 /* GroupNorm (+ optional SiLU) over channels-last rows; the "batch" is whatever shares statistics:
  *   video domain  (resnet.py:180,191; unet.py:504): NB = b,   P = f*h*w   rows per batch
@@ -146,6 +176,11 @@ int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long lo
  * 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
  * kernel, 5 halo-patch conv kernel wherever the conv is eligible, 6 automatic without the halo-patch kernel.
  * High nibble: diagnostic ablation build of the forced kernel (results wrong). */
+/* Which row-resident fused sub-block kernels lavie_unet_forward uses: bit 0 = feed-forward (lavie_geglu_mlp_f16), bit 1 = temporal
+ * attention sub-block; default all.  0 = the one-GEMM-per-launch path (A/B timing, parity cross-checks). */
+int lavie_debug_fused_mask(int mask);
+int lavie_debug_temporal_block_dump(float* buf);   /* development aid: device buffer of 100 * 64 floats, or NULL */
+int lavie_debug_rowfuse_variant(int v);   /* tuning: LDS read-ahead depth of the fused kernels (0 = default) */
 int lavie_debug_force_tile(int mode);
 /* Test/tuning knob: force the split-K factor of the implicit GEMM (0 = automatic). */
 int lavie_debug_force_splits(int s);

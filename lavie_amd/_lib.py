@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LEVELS = 8
 
 c_void_p, c_int, c_float, c_ll, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_char_p
@@ -41,6 +41,15 @@ SIGNATURES = {
                                          c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lavie_pack_temporal_conv_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lavie_pack_geglu_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_int, c_void_p]),
+    "lavie_geglu_mlp_image_bytes": (c_ll, [c_int]),
+    "lavie_geglu_mlp_bias_floats": (c_ll, [c_int]),
+    "lavie_pack_geglu_mlp_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float_p, c_void_p]),
+    "lavie_geglu_mlp_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                     c_float, c_void_p]),
+    "lavie_temporal_block_image_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
+    "lavie_pack_temporal_block_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "lavie_temporal_block_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float_p, c_float_p,
+                                          c_float_p, c_float_p, c_float_p, c_float_p, c_int, c_float, c_float, c_void_p]),
     "lavie_group_norm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float_p, c_float_p, c_float,
                                       c_int, c_float_p, c_void_p, c_void_p]),
     "lavie_group_norm_ws_floats": (c_ll, [c_int, c_int]),
@@ -63,6 +72,9 @@ SIGNATURES = {
     "lavie_latents_to_scaled_model_input1": (c_int, [c_float_p, c_void_p, c_ll, c_float, c_void_p]),
     "lavie_debug_force_tile": (c_int, [c_int]),
     "lavie_debug_force_splits": (c_int, [c_int]),
+    "lavie_debug_fused_mask": (c_int, [c_int]),
+    "lavie_debug_temporal_block_dump": (c_int, [c_void_p]),
+    "lavie_debug_rowfuse_variant": (c_int, [c_int]),
     "lavie_debug_conv_tap_major": (c_int, [c_int]),
     "lavie_debug_attention_qt": (c_int, [c_int]),
     "lavie_debug_temporal_budget": (c_int, [c_int]),

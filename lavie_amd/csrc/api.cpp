@@ -56,6 +56,31 @@ int lavie_linear_f16(const void* A, int lda, const void* W, const float* bias, c
     return launch_igemm(p, false, geglu ? EPI_GEGLU : EPI_LINEAR, S(stream));
 }
 
+long long lavie_geglu_mlp_image_bytes(int C) { return geglu_mlp_supported(C) ? (long long)geglu_mlp_image_bytes(C) : 0; }
+long long lavie_geglu_mlp_bias_floats(int C) { return geglu_mlp_supported(C) ? (long long)geglu_mlp_bias_floats(C) : 0; }
+int lavie_pack_geglu_mlp_f16(const void* w1, const void* b1_f16, const void* w2, int C, void* img, float* b1img, void* stream) {
+    LAVIE_CHECK(w1 && b1_f16 && w2 && img && b1img, "pack_geglu_mlp: null tensor");
+    return pack_geglu_mlp(H(w1), H(b1_f16), H(w2), C, (half_t*)img, b1img, S(stream));
+}
+int lavie_geglu_mlp_f16(const void* x, void* y, int M, int C, const void* img, const float* b1img, const float* gamma,
+                        const float* beta, const float* b2, float eps, void* stream) {
+    return launch_geglu_mlp(H(x), (half_t*)y, M, C, H(img), b1img, gamma, beta, b2, eps, S(stream));
+}
+
+long long lavie_temporal_block_image_bytes(int C, int heads, int F, int rot_dim) {
+    return temporal_block_supported(C, heads, F, rot_dim) ? (long long)temporal_block_image_bytes(C) : 0;
+}
+int lavie_pack_temporal_block_f16(const void* wq, const void* wk, const void* wv, const void* wo, int C, void* img, void* stream) {
+    LAVIE_CHECK(wq && wk && wv && wo && img, "pack_temporal_block: null tensor");
+    return pack_temporal_block(H(wq), H(wk), H(wv), H(wo), C, (half_t*)img, S(stream));
+}
+int lavie_temporal_block_f16(const void* x, void* y, int B, int F, int D, int C, int heads, const void* img, const float* gamma,
+                             const float* beta, const float* bo, const float* relbias, const float* rot_cos,
+                             const float* rot_sin, int rot_dim, float scale, float eps, void* stream) {
+    return launch_temporal_block(H(x), (half_t*)y, B, F, D, C, heads, H(img), gamma, beta, bo, relbias, rot_cos, rot_sin, rot_dim,
+                                 scale, eps, S(stream));
+}
+
 int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void* sc1, int SC1, const void* sc2, int SC2,
                       const void* Wp, const float* bias, const float* bias2, int ldb2, int rows_per_batch, const void* R,
                       void* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const void* zero_page,
@@ -229,6 +254,9 @@ int lavie_debug_force_tile(int mode) { bump_debug_epoch(); igemm_force_tile(mode
 int lavie_debug_force_splits(int s) { bump_debug_epoch(); igemm_force_splits(s); return 0; }
 int lavie_debug_conv_tap_major(int on) { bump_debug_epoch(); g_tap_major = on; return 0; }
 int lavie_debug_attention_qt(int qt) { bump_debug_epoch(); attention_force_qt(qt); return 0; }
+int lavie_debug_rowfuse_variant(int v) { bump_debug_epoch(); rowfuse_set_variant(v); return 0; }
+int lavie_debug_temporal_block_dump(float* buf) { temporal_block_set_debug(buf); return 0; }
+int lavie_debug_fused_mask(int mask) { bump_debug_epoch(); set_fused_mask(mask); return 0; }
 int lavie_debug_temporal_budget(int bytes) { bump_debug_epoch(); temporal_set_budget(bytes); return 0; }
 int lavie_debug_ppx_stamps(unsigned long long* out256) {
     LAVIE_CHECK(out256, "ppx_stamps: null output");

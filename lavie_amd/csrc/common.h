@@ -21,6 +21,8 @@ const char* get_error();
 // kernel-selection debug switches (lavie_debug_*): a process-wide epoch the captured-graph key includes
 void bump_debug_epoch();
 unsigned long debug_epoch();
+void set_fused_mask(int mask);     // which row-resident fused sub-block kernels the engine uses (default: all)
+int fused_mask();
 
 #define LAVIE_CHECK(cond, ...)                 \
     do {                                       \

@@ -22,6 +22,9 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 static unsigned long g_debug_epoch = 0;
+static int g_fused_mask = ~0;          // bit 0: fused feed-forward, bit 1: fused temporal sub-block (A/B switch)
+void set_fused_mask(int m) { g_fused_mask = m; }
+int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
 unsigned long debug_epoch() { return g_debug_epoch; }
 
@@ -386,6 +389,24 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
         RUN(launch_pack_geglu_bias(bias, t->ff1.b, 8 * C, s));
     }
     RUN(pack_linear(b + ".ff.net.2", C, 4 * C, true, &t->ff2, s));
+    if (!cfg_.temporal_plain && !cfg_.vsr_blocks && temporal_block_supported(C, cfg_.heads, 16, cfg_.rotary_dim)) {
+        // fused temporal sub-block (clips of 16 frames): q / k / v / to_out weights in MFMA-fragment order
+        const half_t* wq = given(b + ".attn_" + tname + ".to_q.weight");
+        const half_t* wk = given(b + ".attn_" + tname + ".to_k.weight");
+        const half_t* wv = given(b + ".attn_" + tname + ".to_v.weight");
+        const half_t* wo = given(b + ".attn_" + tname + ".to_out.0.weight");
+        WALLOC(t->tb_img, half_t, temporal_block_image_bytes(C) / sizeof(half_t));
+        RUN(pack_temporal_block(wq, wk, wv, wo, C, t->tb_img, s));
+    }
+    if (geglu_mlp_supported(C)) {      // fused norm3 -> feed-forward -> residual kernel: weight image in MFMA-fragment order
+        const half_t* w1 = given(b + ".ff.net.0.proj.weight");
+        const half_t* b1 = given(b + ".ff.net.0.proj.bias");
+        const half_t* w2 = given(b + ".ff.net.2.weight");
+        NEED(w2, b + ".ff.net.2.weight");
+        WALLOC(t->ff_img, half_t, geglu_mlp_image_bytes(C) / sizeof(half_t));
+        WALLOC(t->ff_b1img, float, geglu_mlp_bias_floats(C));
+        RUN(pack_geglu_mlp(w1, b1, w2, C, t->ff_img, t->ff_b1img, s));
+    }
 
     // LayerNorm-folded projections (norm1 -> attn1 qkv, norm2 -> attn2 q, norm_temp -> attn_temp qkv, norm3 -> GEGLU)
     auto fold = [&](const half_t* W, const NormW& ln, const half_t* bias, int N, half_t** Wf, float** sv, float** bv) -> int {
@@ -602,6 +623,7 @@ static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const fl
     LAVIE_CHECK(K % IGEMM_BK == 0, "linear: K=%d must be a multiple of %d", K, IGEMM_BK);
     p.splits = unsplit ? 1 : igemm_plan_splits(M, N, p.nk, epilogue);
     p.rowstat_out = rowstat ? rowstat->partials : nullptr;
+    p.rowstat_cols = rowstat ? N / rowstat->slots : 0;
     if (fold) { p.ln_stats = fold->stats; p.ln_s = fold->s; }
     const size_t mark = c.ws->mark();
     if (p.splits > 1) {
@@ -773,6 +795,13 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     // its fp16 output, and the projection that consumes LN(tx) runs on raw `tx` with gamma folded into its weights,
     // finishing rstd * (acc - mean * s) + b' in its epilogue — no LayerNorm kernel, no normalised copy in HBM.
     const bool fold = ln_fold_;
+    // base block order: temporal -> feed-forward (attention.py:548-560); interpolation block: feed-forward -> temporal
+    // (interpolation/models/attention.py:592-604)
+    const bool ff_first = cfg_.ff_before_temporal != 0;
+    // row-resident fused sub-blocks (rowfuse.hip), base block order only: they take their LayerNorm statistics from the rows
+    // they hold, so their producers emit none
+    const bool fused_ff = t.ff_img != nullptr && !ff_first && (fused_mask() & 1);
+    const bool fused_t = t.tb_img != nullptr && !ff_first && c.F == 16 && (fused_mask() & 2);
     LnFold lf{nullptr, nullptr};
     RowStat rsd{nullptr, nullptr, C / igemm_rowstat_cols(T, C, C / IGEMM_BK)};
     const RowStat* rowstat = nullptr;
@@ -843,16 +872,21 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = c.ctx_len; a.heads = heads; a.dh = dh; a.kv_batch_div = c.F; a.scale = scale;
         RUN(launch_attention(a, c.s));
     }
-    RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
+    RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, fused_t ? nullptr : rowstat));
 
     // base block order: temporal -> feed-forward (attention.py:548-560); interpolation block: feed-forward -> temporal
     // (interpolation/models/attention.py:592-604)
-    const bool ff_first = cfg_.ff_before_temporal != 0;
     RowStat rsd_ff2 = rsd;
     rsd_ff2.slots = C / igemm_rowstat_cols(T, C, 4 * C / IGEMM_BK);
     const RowStat* rowstat_ff2 = rowstat ? &rsd_ff2 : nullptr;
     auto temporal = [&]() -> int {
         // temporal self-attention over frames, tokens stay in (b f) d order (attention.py:548-555)
+        if (fused_t) {         // norm_temp -> q|k|v -> rotary / bias / softmax / PV -> to_out -> + residual in ONE kernel, in place
+            if (!c.dry)
+                RUN(launch_temporal_block(tx, tx, c.B, c.F, D, C, heads, t.tb_img, t.lnt.g, t.lnt.b, t.ot.b, cur_tables_->relbias[ti],
+                                          cur_tables_->rot_cos, cur_tables_->rot_sin, cfg_.rotary_dim, scale, 1e-5f, c.s));
+            return 0;
+        }
         if (fold) {
             lf.s = t.s_qkvt;
             RUN(linear(c, tx, C, t.f_qkvt, t.b_qkvt, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
@@ -866,13 +900,18 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
             tp.bias = cur_tables_->relbias[ti]; tp.rot_cos = cur_tables_->rot_cos; tp.rot_sin = cur_tables_->rot_sin; tp.rot_dim = cfg_.temporal_plain ? 0 : cfg_.rotary_dim; tp.scale = scale;
             RUN(launch_temporal_attention(tp, c.s));
         }
-        // its output feeds norm3 only in the base order; in the interpolation order proj_out follows (no LayerNorm)
-        RUN(linear(c, att, C, t.ot.w, t.ot.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, ff_first ? nullptr : rowstat));
+        // its output feeds norm3 only in the base order; in the interpolation order proj_out follows (no LayerNorm).
+        // The fused feed-forward kernel takes its LayerNorm statistics from the rows it holds: no partials needed.
+        RUN(linear(c, att, C, t.ot.w, t.ot.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, (ff_first || fused_ff) ? nullptr : rowstat));
         return 0;
     };
     auto feed_forward = [&]() -> int {
         // GEGLU feed-forward (attention.py:558)
-        if (fold) {
+        if (fused_ff) {        // norm3 -> ff1 -> GEGLU -> ff2 -> + residual in ONE kernel, in place on the residual stream
+            LAUNCH(launch_geglu_mlp(tx, tx, T, C, t.ff_img, t.ff_b1img, t.ln3.g, t.ln3.b, t.ff2.b, 1e-5f, c.s));
+            return 0;
+        }
+        if (fold && !fused_t) {       // (the fused temporal kernel emits no row statistics: explicit LayerNorm behind it)
             lf.s = t.s_ff1;
             RUN(linear(c, tx, C, t.f_ff1, t.b_ff1, 8 * C, C, nullptr, wide, 4 * C, T, EPI_GEGLU, &lf));
         } else {

@@ -81,6 +81,9 @@ struct TransformerW {
     half_t* f_q2 = nullptr; float* s_q2 = nullptr; float* b_q2 = nullptr;
     half_t* f_qkvt = nullptr; float* s_qkvt = nullptr; float* b_qkvt = nullptr;
     half_t* f_ff1 = nullptr; float* s_ff1 = nullptr; float* b_ff1 = nullptr;
+    // row-resident fused sub-blocks (rowfuse.hip), built where the width has a kernel (level 0: C = 320)
+    half_t* ff_img = nullptr; float* ff_b1img = nullptr;    // norm3 -> GEGLU feed-forward -> + residual in one kernel
+    half_t* tb_img = nullptr;                               // norm_temp -> q|k|v -> temporal attention -> to_out -> + residual
 };
 
 struct SamplerW { half_t* w = nullptr; float* b = nullptr; int C = 0; };

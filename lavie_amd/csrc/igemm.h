@@ -39,6 +39,8 @@ struct IgemmParams {
     // one pair per 16*NT-column wave tile: rowstat_out[m * rowstat_slots + slot]; the consumer GEMM runs on the RAW
     // rows with gamma folded into W and finishes  y = rstd_m (acc - mean_m s_n) + bias_n  in its epilogue.
     float* rowstat_out;        // [M, N / rowstat_cols, 2] or nullptr (EPI_LINEAR, splits == 1 only)
+    int rowstat_cols;          // columns per slot the caller sized rowstat_out for (igemm_rowstat_cols); launch_igemm checks that
+                               // the kernel it selects writes slots of exactly this width (0 = unchecked)
     const float* ln_stats;     // [M, 2] (mean, rstd) of the A rows (launch_rowstat_finalize), or nullptr
     const float* ln_s;         // [N]: s_n = sum_k W'[n, k]
     int splits;           // split-K factor (1 = none); > 1 needs `slab`

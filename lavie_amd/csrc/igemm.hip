@@ -558,7 +558,13 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
             return launch_igemm_pp_geglu(p, stream);
         return launch_tile<2, 2, 4, 4, 2, false, EPI_GEGLU>(p, stream);
     }
-    if (!gather && ppx_plan(p, epilogue)) return launch_igemm_ppx(p, epilogue, stream);
+    // the row-statistics slot width the caller allocated for must be the wave-tile width of the kernel chosen below (the shape
+    // rule of igemm_rowstat_cols and the eligibility tests here are separate code: a mismatch would write out of range)
+    auto slots_ok = [&](int cols) { return !p.rowstat_out || p.rowstat_cols == 0 || p.rowstat_cols == cols; };
+    if (!gather && ppx_plan(p, epilogue)) {
+        LAVIE_CHECK(slots_ok(pp_bn(p.N) / 4), "igemm: row-statistics slots sized for %d columns, persistent kernel writes %d", p.rowstat_cols, pp_bn(p.N) / 4);
+        return launch_igemm_ppx(p, epilogue, stream);
+    }
     // halo-patch conv kernel: forced (mode 5) or whenever its grid rule holds at this split factor
     if (gather && igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)))) {
         if (int rc = launch_igemm_patch(p, stream)) return rc;
@@ -566,12 +572,14 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     }
     // 160x320 ping-pong kernel: forced (mode 3) or whenever the planner's rule holds for this problem at its split factor
     if ((lo == 3 && p.N % 320 == 0) || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits))) {
+        LAVIE_CHECK(slots_ok(pp_bn(p.N) / 4), "igemm: row-statistics slots sized for %d columns, ping-pong kernel writes %d", p.rowstat_cols, pp_bn(p.N) / 4);
         if (int rc = launch_igemm_pp(p, gather, stream)) return rc;
         return reduce_splits();
     }
     // 128-row kernel: two independent workgroups per CU, tile width by grid quantisation
     const int bn = igemm_pick_bn(p.M, p.N, p.splits);
     LAVIE_CHECK(bn != 0, "igemm: N=%d is not a multiple of 64", p.N);
+    LAVIE_CHECK(slots_ok(bn / 2), "igemm: row-statistics slots sized for %d columns, 128-row kernel writes %d", p.rowstat_cols, bn / 2);
     if (bn == 160) {
         if (g_force_tile >= 0x10 && lo == 1) {          // diagnostic ablations of the 128x160 tile (results wrong)
             const int abl = g_force_tile >> 4;

@@ -87,6 +87,25 @@ int launch_ln_fold(const half_t* W, const float* gamma, const float* beta, const
                    float* b_out, int N, int K, hipStream_t stream);
 int launch_pack_geglu_vec(const float* in, float* out, int N, hipStream_t stream);
 
+// ---- rowfuse.hip : row-resident fused transformer sub-blocks (weights streamed through LDS, rows in registers)
+void rowfuse_set_variant(int v);   // tuning knob: LDS read-ahead depth (0 = default)
+bool geglu_mlp_supported(int C);
+size_t geglu_mlp_image_bytes(int C);
+size_t geglu_mlp_bias_floats(int C);
+int pack_geglu_mlp(const half_t* w1, const half_t* b1, const half_t* w2, int C, half_t* img, float* b1img, hipStream_t stream);
+// y = x + W2 (h * gelu(g)) + b2, (h, g) = W1 LN(x) + b1; y may alias x
+int launch_geglu_mlp(const half_t* x, half_t* y, int M, int C, const half_t* img, const float* b1img, const float* gamma,
+                     const float* beta, const float* b2, float eps, hipStream_t stream);
+
+// x' = x + to_out(attn_temp(LN(x))) for clips of exactly 16 frames, rows in (b f) d order; y may alias x
+void temporal_block_set_debug(float* buf);   // development aid: register-tile dump of workgroup 0 (nullptr = off)
+bool temporal_block_supported(int C, int heads, int F, int rot_dim);
+size_t temporal_block_image_bytes(int C);
+int pack_temporal_block(const half_t* wq, const half_t* wk, const half_t* wv, const half_t* wo, int C, half_t* img, hipStream_t stream);
+int launch_temporal_block(const half_t* x, half_t* y, int B, int F, int D, int C, int heads, const half_t* img,
+                          const float* gamma, const float* beta, const float* bo, const float* relbias, const float* rot_cos,
+                          const float* rot_sin, int rot_dim, float scale, float eps, hipStream_t stream);
+
 // host-only helper (no GPU): T5-style bucket of (query i, key j), attention.py:681-699
 void relpos_bucket_table(int F, int num_buckets, int max_distance, int* out);
 

@@ -72,6 +72,60 @@ def pack_geglu(weight, bias):
     return w_out, b_out
 
 
+def pack_geglu_mlp(w1, b1, w2):
+    """ff.net.0.proj.weight [8C, C], .bias [8C], ff.net.2.weight [C, 4C] (fp16, device) -> (image, bias image) of the fused
+    feed-forward kernel (lavie_geglu_mlp_f16).  Raises for a width the kernel is not built for."""
+    _chk16(w1, b1, w2)
+    C = w2.shape[0]
+    lib = _lib.load()
+    nbytes = lib.lavie_geglu_mlp_image_bytes(C)
+    if nbytes == 0 or tuple(w1.shape) != (8 * C, C) or tuple(w2.shape) != (C, 4 * C):
+        raise RuntimeError(f"geglu_mlp: width {C} is not built (or weight shapes do not match)")
+    img = torch.empty(nbytes // 2, dtype=torch.float16, device=w1.device)
+    b1img = torch.empty(lib.lavie_geglu_mlp_bias_floats(C), dtype=torch.float32, device=w1.device)
+    _lib.check(lib.lavie_pack_geglu_mlp_f16(_p(w1), _p(b1), _p(w2), C, _p(img), _p(b1img), _stream()), "lavie_pack_geglu_mlp_f16")
+    return img, b1img
+
+
+def geglu_mlp(x, img, b1img, gamma, beta, b2, eps=1e-5, out=None):
+    """x + FeedForward_GEGLU(LayerNorm(x)) in one kernel (attention.py:558); `out` may be x itself."""
+    _chk16(x, img, out)
+    _chk32(b1img, gamma, beta, b2)
+    M, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().lavie_geglu_mlp_f16(_p(x), _p(out), M, C, _p(img), _p(b1img), _p(gamma), _p(beta), _p(b2), eps,
+                                               _stream()), "lavie_geglu_mlp_f16")
+    return out
+
+
+def pack_temporal_block(wq, wk, wv, wo, heads=8, frames=16, rot_dim=32):
+    """attn_temp.to_q / to_k / to_v / to_out.0 weights [C, C] (fp16, device) -> the weight image of the fused temporal
+    sub-block kernel (lavie_temporal_block_f16).  Raises for a configuration the kernel is not built for."""
+    _chk16(wq, wk, wv, wo)
+    C = wq.shape[0]
+    lib = _lib.load()
+    nbytes = lib.lavie_temporal_block_image_bytes(C, heads, frames, rot_dim)
+    if nbytes == 0:
+        raise RuntimeError(f"temporal_block: C={C} heads={heads} frames={frames} rot_dim={rot_dim} is not built")
+    img = torch.empty(nbytes // 2, dtype=torch.float16, device=wq.device)
+    _lib.check(lib.lavie_pack_temporal_block_f16(_p(wq), _p(wk), _p(wv), _p(wo), C, _p(img), _stream()), "lavie_pack_temporal_block_f16")
+    return img
+
+
+def temporal_block(x, img, gamma, beta, bo, relbias, rot_cos, rot_sin, B, F, D, heads, rot_dim, scale, eps=1e-5, out=None):
+    """x + to_out(attn_temp(norm_temp(x))) on token rows [(b f) d, C] in one kernel (attention.py:548-555, 580-667)."""
+    _chk16(x, img, out)
+    _chk32(gamma, beta, bo, relbias, rot_cos, rot_sin)
+    C = x.shape[1]
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().lavie_temporal_block_f16(_p(x), _p(out), B, F, D, C, heads, _p(img), _p(gamma), _p(beta), _p(bo),
+                                                    _p(relbias), _p(rot_cos), _p(rot_sin), rot_dim, scale, eps, _stream()),
+               "lavie_temporal_block_f16")
+    return out
+
+
 def pack_conv3x3(weight, shortcut_weight=None):
     """[Cout, Cin, 3, 3] (+ optional 1x1 shortcut [Cout, Csc, 1, 1]) -> [Cout, 9*Cin (+ Csc)]."""
     _chk16(weight, shortcut_weight)

@@ -1,0 +1,94 @@
+"""-m gpu: the row-resident fused transformer sub-blocks (lavie_amd/csrc/rowfuse.hip) through the C ABI against fp32 CPU
+restatements of the reference lines they replace."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import TOL_OP, f32, h16, q16, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# 128 rows = one workgroup pass; 2608 = 20 passes + a ragged one (48 rows: five waves idle, clamped loads);
+# 40960 = 320 passes on 256 persistent workgroups (some run two passes: the weight ring wraps across passes)
+@pytest.mark.parametrize("M", [128, 2608, 40960])
+def test_geglu_mlp_fused(M):
+    """hidden_states = self.ff(self.norm3(hidden_states)) + hidden_states (attention.py:558; FeedForward / GEGLU:
+    vsr/models/diffusers_attention.py:734-822) as one kernel, C = 320 (level 0 of the base UNet)."""
+    from lavie_amd import ops
+    C = 320
+    g = gen(M)
+    x = q16(torch.randn(M, C, generator=g) * 1.5 + 0.3 * torch.randn(1, C, generator=g))
+    w1 = q16(torch.randn(8 * C, C, generator=g) / math.sqrt(C))
+    b1 = q16(torch.randn(8 * C, generator=g) * 0.2)
+    w2 = q16(torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C))
+    b2 = torch.randn(C, generator=g) * 0.2
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ln = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    h, gate = (ln @ w1.t() + b1).chunk(2, dim=-1)
+    delta = (h * F.gelu(gate)) @ w2.t() + b2
+    ref = x + delta
+    img, b1img = ops.pack_geglu_mlp(h16(w1), h16(b1), h16(w2))
+    xd = h16(x)
+    got = ops.geglu_mlp(xd, img, b1img, f32(gamma), f32(beta), f32(b2))
+    assert rel_l2(got, ref) < TOL_OP
+    assert rel_l2(got.float().cpu() - x, delta) < 4e-3            # the residual must not hide an error in the product
+    got2 = ops.geglu_mlp(xd, img, b1img, f32(gamma), f32(beta), f32(b2))
+    assert torch.equal(got, got2)                                  # no atomics, fixed order: bit-reproducible
+    ops.geglu_mlp(xd, img, b1img, f32(gamma), f32(beta), f32(b2), out=xd)      # in place, as the engine runs it
+    assert torch.equal(xd, got)
+
+
+def test_geglu_mlp_rejects_unbuilt_width():
+    from lavie_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.pack_geglu_mlp(torch.zeros(8 * 256, 256, dtype=torch.float16, device="cuda"),
+                           torch.zeros(8 * 256, dtype=torch.float16, device="cuda"),
+                           torch.zeros(256, 4 * 256, dtype=torch.float16, device="cuda"))
+
+
+# 24 pixels = three workgroup passes worth on a 3-workgroup grid .. no: grid = min(pixels, 256): 24 pixels -> 24 workgroups of one
+# pixel (seven idle waves each); 700 pixels -> 256 workgroups with 2-3 pixels; 5120 = the bench's level-0 shape (20 pixels per
+# workgroup: passes of 8 + 8 + 4, the weight ring restarts at every pass)
+@pytest.mark.parametrize("B,D", [(2, 12), (1, 700), (2, 2560)])
+def test_temporal_block_fused(B, D):
+    """hidden_states = self.attn_temp(self.norm_temp(hidden_states)) + hidden_states between the two rearranges of
+    BasicTransformerBlock.forward (attention.py:548-555), TemporalAttention.forward / _attention (:580-667) — as one kernel on
+    token rows in (b f) d order, against the oracle's restatement (pinned to the imported reference class in
+    tests/test_oracle_vs_reference.py::test_temporal_attention)."""
+    from lavie_amd import ops
+    from oracle import unet_fp32 as O
+    C, heads, Fr = 320, 8, 16
+    cfg = O.UNetConfig()
+    g = gen(B * 1000 + D)
+    sd = {"to_q.weight": q16(torch.randn(C, C, generator=g) / math.sqrt(C)),
+          "to_k.weight": q16(torch.randn(C, C, generator=g) / math.sqrt(C)),
+          "to_v.weight": q16(torch.randn(C, C, generator=g) / math.sqrt(C)),
+          "to_out.0.weight": q16(torch.randn(C, C, generator=g) / math.sqrt(C)),
+          "to_out.0.bias": torch.randn(C, generator=g) * 0.2,
+          "time_rel_pos_bias.relative_attention_bias.weight": q16(torch.randn(cfg.rel_buckets, heads, generator=g))}
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    x = q16(torch.randn(B * Fr * D, C, generator=g) * 1.5 + 0.3 * torch.randn(1, C, generator=g))
+    xr = x.reshape(B, Fr, D, C).permute(0, 2, 1, 3).reshape(B * D, Fr, C)                      # (b f) d c -> (b d) f c (:550)
+    delta = O.temporal_attention(sd, "", F.layer_norm(xr, (C,), gamma, beta, 1e-5), cfg)
+    back = lambda t: t.reshape(B, D, Fr, C).permute(0, 2, 1, 3).reshape(B * Fr * D, C)          # (:555)
+    ref, delta = back(xr + delta), back(delta)
+    inv = 10000.0 ** (-torch.arange(0, 32, 2, dtype=torch.float32) / 32)
+    ang = torch.arange(Fr, dtype=torch.float32).reshape(Fr, 1) * inv.reshape(1, -1)
+    relbias = O.rel_pos_bias(sd, "", Fr, cfg).contiguous()
+    img = ops.pack_temporal_block(h16(sd["to_q.weight"]), h16(sd["to_k.weight"]), h16(sd["to_v.weight"]), h16(sd["to_out.0.weight"]))
+    xd = h16(x)
+    args = (img, f32(gamma), f32(beta), f32(sd["to_out.0.bias"]), f32(relbias), f32(ang.cos()), f32(ang.sin()), B, Fr, D, heads, 32,
+            (C // heads) ** -0.5)
+    got = ops.temporal_block(xd, *args)
+    assert rel_l2(got, ref) < TOL_OP
+    assert rel_l2(got.float().cpu() - x, delta) < 4e-3
+    assert torch.equal(got, ops.temporal_block(xd, *args))          # bit-reproducible
+    ops.temporal_block(xd, *args, out=xd)                           # in place, as the engine runs it
+    assert torch.equal(xd, got)
