@@ -45,7 +45,7 @@ ATTN2_KV_TFLOP = 0.0945       # of which: the attn2 to_k / to_v projections of t
 PEAK_MFMA_TFLOPS = 2500.0     # dense fp16, gfx950 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 CLASS_NAMES = ["conv3x3_igemm", "linear_igemm", "attention", "temporal_attention", "group_norm", "layer_norm", "other",
-               "conv3x3_patch_kernel(subset of conv3x3_igemm)"]
+               "conv3x3_patch_kernel(subset of conv3x3_igemm)", "fused_temporal_sub_block", "fused_feed_forward"]
 
 
 def synth_inputs(idx, device):
@@ -328,7 +328,7 @@ def main():
     if use_prof:   # the dominant kernel and temporal attention only, with events attached to the kernel launches themselves
         # (hipExtLaunchKernelGGL: no extra packets).  Scope-style hipEventRecord pairs cost ~11 us of stream time each:
         # instrumenting every class that way (~270 pairs per forward) slowed the timed region by 7 % (measured).
-        profile_begin(lib, (1 << 7) | (1 << 3), 2 * 40 * args.ddpm_steps * args.steps + 1024)
+        profile_begin(lib, (1 << 7) | (1 << 3) | (1 << 8) | (1 << 9), 2 * 60 * args.ddpm_steps * args.steps + 1024)
     t0 = time.perf_counter()
     outs = [one_video(args.warmup + i) for i in range(args.steps)]
     local_lat = torch.cat(outs, dim=0).to(torch.float16)
@@ -416,6 +416,21 @@ def main():
                                            "traffic": None, "launches": temp["launches"],
                                            "avg_launch_us": 1e3 * temp["ms"] / temp["launches"],
                                            "bytes_per_launch": temp["bytes"] / temp["launches"]}
+        for key, row, what, ref in (
+                ("roofline_fused_temporal", timed[8],
+                 "temporal_block_kernel (level 0: norm_temp + q|k|v projections + rotary / bias / softmax / PV + to_out + residual in ONE launch; "
+                 "rows stay in registers, only weights cross LDS)", "attention.py:548-555, 580-667"),
+                ("roofline_fused_feed_forward", timed[9],
+                 "geglu_mlp_kernel (level 0: norm3 + ff1 + GEGLU + ff2 + residual in ONE launch; the [T, 4C] intermediate never exists)",
+                 "attention.py:558")):
+            if row["launches"]:
+                tf = row["flops"] / (row["ms"] * 1e-3) / 1e12
+                bw = row["bytes"] / (row["ms"] * 1e-3) / 1e9
+                result[key] = {"kernel": what, "replaces": ref, "bound": "mfma", "achieved": tf, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / PEAK_MFMA_TFLOPS, "launches": row["launches"], "avg_launch_us": 1e3 * row["ms"] / row["launches"],
+                               # SURVEY §8d's fused definition of the algorithmic bytes: x in + x' out + the weights once
+                               "algorithmic_bytes_per_launch": row["bytes"] / row["launches"], "hbm_achieved_gbs": bw,
+                               "hbm_frac": bw / PEAK_HBM_GBS}
         if os.path.isfile(pmc):
             tr = json.load(open(pmc))
             for key in ("roofline", "roofline_temporal"):
@@ -431,7 +446,7 @@ def main():
         x2 = torch.cat([lat, lat]).half().contiguous()
         net(x2, 500, encoder_hidden_states=ctx)
         torch.cuda.synchronize()
-        profile_begin(lib, 0xFF, 4096)
+        profile_begin(lib, 0x3FF, 4096)
         t1 = time.perf_counter()
         net(x2, 500, encoder_hidden_states=ctx)
         rows = profile_end(lib)

@@ -167,11 +167,12 @@ int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long lo
  * Measurement hook: HIP-event timing per kernel class on the launch stream (bench.py's roofline leg).
  * Classes: 0 conv3x3 (implicit GEMM, gathered), 1 linear/1x1/GEGLU GEMM, 2 spatial+text attention core,
  * 3 temporal attention core, 4 GroupNorm, 5 LayerNorm, 6 other, 7 the halo-patch conv kernel alone (a subset of
- * class 0: the events bracket exactly that kernel's launches).  lavie_profile_end synchronises the
+ * class 0: the events bracket exactly that kernel's launches), 8 the fused temporal sub-block kernel, 9 the fused feed-forward
+ * kernel (both with events attached to the kernel launch itself).  lavie_profile_end synchronises the
  * stream and fills four host arrays of LAVIE_PROFILE_CLASSES entries (launches, milliseconds,
  * algorithmic flops, algorithmic bytes — the per-launch figures are defined in DESIGN.md).
  * ---------------------------------------------------------------------------------------------- */
-#define LAVIE_PROFILE_CLASSES 8
+#define LAVIE_PROFILE_CLASSES 10
 /* Test/tuning knob for the implicit-GEMM kernel choice.  Low nibble: 0 automatic, 1 128-row kernel with the widest tile,
  * 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
  * kernel, 5 halo-patch conv kernel wherever the conv is eligible, 6 automatic without the halo-patch kernel.
@@ -180,6 +181,7 @@ int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long lo
  * attention sub-block; default all.  0 = the one-GEMM-per-launch path (A/B timing, parity cross-checks). */
 int lavie_debug_fused_mask(int mask);
 int lavie_debug_temporal_block_dump(float* buf);   /* development aid: device buffer of 100 * 64 floats, or NULL */
+int lavie_debug_rowfuse_stamps(unsigned long long* buf);   /* stamp build (variant 7): device buffer of 64 u64, or NULL */
 int lavie_debug_rowfuse_variant(int v);   /* tuning: LDS read-ahead depth of the fused kernels (0 = default) */
 int lavie_debug_force_tile(int mode);
 /* Test/tuning knob: force the split-K factor of the implicit GEMM (0 = automatic). */

@@ -75,6 +75,7 @@ SIGNATURES = {
     "lavie_debug_fused_mask": (c_int, [c_int]),
     "lavie_debug_temporal_block_dump": (c_int, [c_void_p]),
     "lavie_debug_rowfuse_variant": (c_int, [c_int]),
+    "lavie_debug_rowfuse_stamps": (c_int, [c_void_p]),
     "lavie_debug_conv_tap_major": (c_int, [c_int]),
     "lavie_debug_attention_qt": (c_int, [c_int]),
     "lavie_debug_temporal_budget": (c_int, [c_int]),

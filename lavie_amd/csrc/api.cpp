@@ -254,6 +254,7 @@ int lavie_debug_force_tile(int mode) { bump_debug_epoch(); igemm_force_tile(mode
 int lavie_debug_force_splits(int s) { bump_debug_epoch(); igemm_force_splits(s); return 0; }
 int lavie_debug_conv_tap_major(int on) { bump_debug_epoch(); g_tap_major = on; return 0; }
 int lavie_debug_attention_qt(int qt) { bump_debug_epoch(); attention_force_qt(qt); return 0; }
+int lavie_debug_rowfuse_stamps(unsigned long long* buf) { rowfuse_set_stamp_buffer(buf); return 0; }
 int lavie_debug_rowfuse_variant(int v) { bump_debug_epoch(); rowfuse_set_variant(v); return 0; }
 int lavie_debug_temporal_block_dump(float* buf) { temporal_block_set_debug(buf); return 0; }
 int lavie_debug_fused_mask(int mask) { bump_debug_epoch(); set_fused_mask(mask); return 0; }

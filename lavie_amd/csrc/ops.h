@@ -88,6 +88,7 @@ int launch_ln_fold(const half_t* W, const float* gamma, const float* beta, const
 int launch_pack_geglu_vec(const float* in, float* out, int N, hipStream_t stream);
 
 // ---- rowfuse.hip : row-resident fused transformer sub-blocks (weights streamed through LDS, rows in registers)
+void rowfuse_set_stamp_buffer(unsigned long long* buf);   // stamp build (variant 7): [8 waves][8] cycle sums, or nullptr
 void rowfuse_set_variant(int v);   // tuning knob: LDS read-ahead depth (0 = default)
 bool geglu_mlp_supported(int C);
 size_t geglu_mlp_image_bytes(int C);

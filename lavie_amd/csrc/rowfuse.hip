@@ -20,6 +20,8 @@
 //   (/root/reference/base/models/attention.py:558; spec /root/reference/vsr/models/diffusers_attention.py:801-822) with its
 //   LayerNorm (attention.py:480) and residual.  Per 32 hidden units: 4 tiles x 10 k-steps of W1 (value / gate rows of the two
 //   16-unit halves), GEGLU in registers, the 32 products become ONE B fragment, 20 tiles of W2 accumulate into the residual.
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -134,6 +136,7 @@ struct GegluMlpParams {
     int M;
     int tiles;               // 16-row tiles = ceil(M / 16), dealt to the workgroups in contiguous, near-equal runs
     float eps;
+    unsigned long long* stamps;   // stamp build only: [8 waves][8] cycle sums of workgroup 0
 };
 
 __device__ __forceinline__ void rf_dma(const char* src, char* lds) {
@@ -183,9 +186,22 @@ __device__ __forceinline__ void rf_run(unsigned addr, Fn&& fn) {
 
 // ABL: timing-only ablation builds (results wrong): 1 = half the LDS fragment reads, 2 = no GELU arithmetic, 3 = no LDS-DMA
 // after the first two groups, 4 = no barriers inside the pass
+// ABL 5: stamp build (s_memtime around the phases of the chunk loop; sums per wave of workgroup 0 go to p.stamps; read the SHARES)
+__device__ __forceinline__ unsigned long long rf_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 template <int C, int PF, int ABL = 0>
 __global__ __launch_bounds__(rf::THREADS, 2) void geglu_mlp_kernel(const GegluMlpParams p) {
     using namespace rf;
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;      // DMA issue, first product, geglu, second product, prologue, store, vmcnt wait, barrier
+    auto mark = [&](int which) {
+        if constexpr (ABL == 5) { const unsigned long long t = rf_stamp(); st[which] += t - t0; t0 = t; }
+    };
+    if constexpr (ABL == 5) t0 = rf_stamp();
     constexpr int NT = C / 16;                    // residual tiles per token tile (20)
     constexpr int KS = C / 32;                    // k-steps of the first product (10)
     constexpr int CHUNKS = C / 8;                 // 32-unit hidden chunks (40)
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(rf::THREADS, 2) void geglu_mlp_kernel(const GegluMl
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ring = smem;
     float* const b1s = reinterpret_cast<float*>(smem + RING_BYTES);           // [CHUNKS][4][16]
+    float* const vec = b1s + CHUNKS * 64;                                     // gamma | beta | second-layer bias, C floats each
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(rf::THREADS, 2) void geglu_mlp_kernel(const GegluMl
 
     // first-layer bias image -> LDS once (plain stores: no LDS-DMA is in flight yet)
     for (int i = tid; i < CHUNKS * 64; i += THREADS) b1s[i] = p.b1img[i];
+    for (int i = tid; i < C; i += THREADS) { vec[i] = p.gamma[i]; vec[C + i] = p.beta[i]; vec[2 * C + i] = p.b2[i]; }
 
     // this workgroup's run of 16-row tiles: near-equal shares, 8 per pass (one per wave); the last pass may leave waves
     // without a tile (they keep moving weights and meeting barriers).  81920 rows on 256 workgroups = 20 tiles each = passes
@@ -228,7 +246,9 @@ __global__ __launch_bounds__(rf::THREADS, 2) void geglu_mlp_kernel(const GegluMl
         __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < total_groups && ABL != 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mark(6);
         if (ABL != 4) __builtin_amdgcn_s_barrier();
+        mark(7);
         __builtin_amdgcn_sched_barrier(0);
         issue_group(g + 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -269,21 +289,35 @@ __global__ __launch_bounds__(rf::THREADS, 2) void geglu_mlp_kernel(const GegluMl
         sq += __shfl_xor(sq, 32, 64);
         const float rstd = rsqrtf(sq * (1.0f / C) + p.eps);
         half8_t xb[KS];
+        // The LayerNorm vectors and the second-layer bias come from LDS (round 3, stamp build: read from global memory they cost
+        // ~35 dependent L2 round trips behind vmcnt(0) each — 21 % of the kernel).  The base is an opaque 32-bit offset renewed
+        // every pass (else hipcc hoists sixty per-lane addresses out of the loop), fenced every two k-steps (else it requests
+        // all sixty vectors at once and spills), and every result is pinned where it is computed (else it is sunk to its first use).
+        unsigned vec_off = (unsigned)(size_t)LDS_PTR(vec + 4 * q);
+        asm volatile("" : "+v"(vec_off));
+        auto lds_f4 = [](unsigned off) { return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((size_t)off); };
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + 32 * s + 4 * q);
-            const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.gamma + 32 * s + 16 + 4 * q);
-            const f32x4 e0 = *reinterpret_cast<const f32x4*>(p.beta + 32 * s + 4 * q);
-            const f32x4 e1 = *reinterpret_cast<const f32x4*>(p.beta + 32 * s + 16 + 4 * q);
+            if (s % 2 == 0 && s > 0) __builtin_amdgcn_sched_barrier(0);
+            const f32x4 g0 = lds_f4(vec_off + (32 * s) * 4), g1 = lds_f4(vec_off + (32 * s + 16) * 4);
+            const f32x4 e0 = lds_f4(vec_off + (C + 32 * s) * 4), e1 = lds_f4(vec_off + (C + 32 * s + 16) * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xb[s][r] = (half_t)((R[2 * s][r] - mean) * rstd * g0[r] + e0[r]);
                 xb[s][4 + r] = (half_t)((R[2 * s + 1][r] - mean) * rstd * g1[r] + e1[r]);
             }
+            asm volatile("" : "+v"(xb[s]));
         }
         // second-layer bias joins the residual now: x + b2 + W2 h accumulates in place
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) R[t] += *reinterpret_cast<const f32x4*>(p.b2 + 16 * t + 4 * q);
+        for (int t = 0; t < NT; ++t) {
+            if (t % 5 == 0 && t > 0) __builtin_amdgcn_sched_barrier(0);
+            R[t] += lds_f4(vec_off + (2 * C + 16 * t) * 4);
+            asm volatile("" : "+v"(R[t]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- 40 hidden chunks, two per ring revolution (pieces 0..59 / 60..119 of the ring).  Two accumulator sets: the
         // first product of chunk cc + 1 does not wait for the GEGLU of chunk cc.
@@ -323,17 +357,28 @@ __global__ __launch_bounds__(rf::THREADS, 2) void geglu_mlp_kernel(const GegluMl
         using I0 = std::integral_constant<int, 0>;
         using I2 = std::integral_constant<int, 2>;
         using I4 = std::integral_constant<int, 4>;
+        mark(4);
         for (int cc = 0; cc < CHUNKS; cc += 2) {
             sync_group(g++);                              // ring pieces 0..39: W1 of chunk cc
+            mark(0);
             first_product(accA, cc, ring_lo, I0{}, I4{});
+            mark(1);
             sync_group(g++);                              // 40..79: W2 of chunk cc, v0 g0 of chunk cc + 1
+            mark(0);
             first_product(accB, cc + 1, ring_hi, I0{}, I2{});
+            mark(1);
             geglu(accA);
+            mark(2);
             second_product(ring_lo);
+            mark(3);
             sync_group(g++);                              // 80..119: v1 g1 and W2 of chunk cc + 1
+            mark(0);
             first_product(accB, cc + 1, ring_hi, I2{}, I4{});
+            mark(1);
             geglu(accB);
+            mark(2);
             second_product(ring_hi);
+            mark(3);
         }
         // ---- x' = residual registers, one rounding
         if (active && row < p.M) {
@@ -344,14 +389,22 @@ __global__ __launch_bounds__(rf::THREADS, 2) void geglu_mlp_kernel(const GegluMl
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (ABL == 5) {
+        mark(5);
+        if (blockIdx.x == 0 && lane == 0 && p.stamps) {
+            for (int i = 0; i < 8; ++i) p.stamps[wave * 8 + i] = st[i];
+        }
+    }
 }
 
+static unsigned long long* g_rf_stamps = nullptr;
+void rowfuse_set_stamp_buffer(unsigned long long* buf) { g_rf_stamps = buf; }
 static int g_rf_variant = 0;            // tuning: LDS read-ahead depth of the fused kernels (0 = default)
 void rowfuse_set_variant(int v) { g_rf_variant = v; }
 
 template <int PF, int ABL = 0>
-static int launch_geglu_mlp_t(const GegluMlpParams& p, hipStream_t stream) {
-    constexpr int lds = rf::RING_BYTES + (320 / 8) * 64 * 4;
+static int launch_geglu_mlp_t(const GegluMlpParams& p, hipStream_t stream, const ProfileScope& prof) {
+    constexpr int lds = rf::RING_BYTES + (320 / 8) * 64 * 4 + 3 * 320 * 4;
     auto kern = geglu_mlp_kernel<320, PF, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -359,7 +412,8 @@ static int launch_geglu_mlp_t(const GegluMlpParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int grid = p.tiles < 256 ? p.tiles : 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(rf::THREADS), lds, stream, p);
+    if (prof.active()) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(rf::THREADS), lds, stream, prof.start(), prof.stop(), 0, p);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(rf::THREADS), lds, stream, p);
     LAVIE_HIP(hipGetLastError());
     return 0;
 }
@@ -368,18 +422,20 @@ int launch_geglu_mlp(const half_t* x, half_t* y, int M, int C, const half_t* img
                      const float* beta, const float* b2, float eps, hipStream_t stream) {
     LAVIE_CHECK(geglu_mlp_supported(C), "geglu_mlp: width %d is not built (320 only)", C);
     LAVIE_CHECK(x && y && img && b1img && gamma && beta && b2 && M > 0, "geglu_mlp: bad arguments");
-    ProfileScope prof(KC_LINEAR, stream, 2.0 * M * (double)C * 12.0 * C, 2.0 * (2.0 * M * C + 12.0 * C * C));
+    // algorithmic work: both products; bytes: x in, x' out, the weights once
+    ProfileScope prof(KC_FUSED_FF, stream, 2.0 * M * (double)C * 12.0 * C, 2.0 * (2.0 * M * C + 12.0 * C * C), /*kernel_events=*/true);
     GegluMlpParams p;
     p.x = x; p.y = y; p.img = img; p.b1img = b1img; p.gamma = gamma; p.beta = beta; p.b2 = b2;
-    p.M = M; p.tiles = cdiv(M, rf::TOK); p.eps = eps;
+    p.M = M; p.tiles = cdiv(M, rf::TOK); p.eps = eps; p.stamps = g_rf_stamps;
     switch (g_rf_variant) {
-        case 1: return launch_geglu_mlp_t<5>(p, stream);
-        case 2: return launch_geglu_mlp_t<12>(p, stream);
-        case 3: return launch_geglu_mlp_t<8, 1>(p, stream);
-        case 4: return launch_geglu_mlp_t<8, 2>(p, stream);
-        case 5: return launch_geglu_mlp_t<8, 3>(p, stream);
-        case 6: return launch_geglu_mlp_t<8, 4>(p, stream);
-        default: return launch_geglu_mlp_t<8>(p, stream);
+        case 1: return launch_geglu_mlp_t<5>(p, stream, prof);
+        case 2: return launch_geglu_mlp_t<12>(p, stream, prof);
+        case 3: return launch_geglu_mlp_t<8, 1>(p, stream, prof);
+        case 4: return launch_geglu_mlp_t<8, 2>(p, stream, prof);
+        case 5: return launch_geglu_mlp_t<8, 3>(p, stream, prof);
+        case 6: return launch_geglu_mlp_t<8, 4>(p, stream, prof);
+        case 7: return launch_geglu_mlp_t<8, 5>(p, stream, prof);      // stamp build
+        default: return launch_geglu_mlp_t<8>(p, stream, prof);
     }
 }
 
@@ -847,7 +903,8 @@ int launch_temporal_block(const half_t* x, half_t* y, int B, int F, int D, int C
     LAVIE_CHECK(temporal_block_supported(C, heads, F, rot_dim), "temporal_block: C=%d heads=%d F=%d rot_dim=%d is not built", C, heads, F, rot_dim);
     LAVIE_CHECK(x && y && img && gamma && beta && bo && relbias && rot_cos && rot_sin && B > 0 && D > 0, "temporal_block: bad arguments");
     const double tok = (double)B * F * D;
-    ProfileScope prof(KC_LINEAR, stream, 2.0 * tok * C * 4.0 * C + 4.0 * tok * F * C, 2.0 * (2.0 * tok * C + 4.0 * C * C));
+    // algorithmic work: four C x C projections + the attention core; bytes (fused definition): x in, x' out, weights once
+    ProfileScope prof(KC_FUSED_TEMPORAL, stream, 2.0 * tok * C * 4.0 * C + 4.0 * tok * F * C, 2.0 * (2.0 * tok * C + 4.0 * C * C), /*kernel_events=*/true);
     TemporalBlockParams p;
     p.x = x; p.y = y; p.img = img; p.gamma = gamma; p.beta = beta; p.bo = bo; p.relbias = relbias; p.rot_cos = rot_cos;
     p.rot_sin = rot_sin; p.D = D; p.units = B * D; p.scale = scale; p.eps = eps; p.dbg = g_tb_dbg;
@@ -855,7 +912,8 @@ int launch_temporal_block(const half_t* x, half_t* y, int B, int F, int D, int C
     const int grid = p.units < 256 ? p.units : 256;
     auto go = [&](auto kern) -> int {
         LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(rf::THREADS), lds, stream, p);
+        if (prof.active()) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(rf::THREADS), lds, stream, prof.start(), prof.stop(), 0, p);
+        else hipLaunchKernelGGL(kern, dim3(grid), dim3(rf::THREADS), lds, stream, p);
         LAVIE_HIP(hipGetLastError());
         return 0;
     };
