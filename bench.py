@@ -433,7 +433,7 @@ def main():
                                "hbm_frac": bw / PEAK_HBM_GBS}
         if os.path.isfile(pmc):
             tr = json.load(open(pmc))
-            for key in ("roofline", "roofline_temporal"):
+            for key in ("roofline", "roofline_temporal", "roofline_fused_temporal", "roofline_fused_feed_forward"):
                 if key in result and key in tr:
                     result[key]["traffic"] = tr[key]
                     result[key]["traffic_source"] = ("profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
