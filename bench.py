@@ -45,7 +45,8 @@ ATTN2_KV_TFLOP = 0.0945       # of which: the attn2 to_k / to_v projections of t
 PEAK_MFMA_TFLOPS = 2500.0     # dense fp16, gfx950 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 CLASS_NAMES = ["conv3x3_igemm", "linear_igemm", "attention", "temporal_attention", "group_norm", "layer_norm", "other",
-               "conv3x3_patch_kernel(subset of conv3x3_igemm)", "fused_temporal_sub_block", "fused_feed_forward"]
+               "conv3x3_patch_kernel(subset of conv3x3_igemm)", "fused_temporal_sub_block", "fused_feed_forward",
+               "fused_text_cross_attention_sub_block"]
 
 
 def synth_inputs(idx, device):
@@ -328,7 +329,7 @@ def main():
     if use_prof:   # the dominant kernel and temporal attention only, with events attached to the kernel launches themselves
         # (hipExtLaunchKernelGGL: no extra packets).  Scope-style hipEventRecord pairs cost ~11 us of stream time each:
         # instrumenting every class that way (~270 pairs per forward) slowed the timed region by 7 % (measured).
-        profile_begin(lib, (1 << 7) | (1 << 3) | (1 << 8) | (1 << 9), 2 * 60 * args.ddpm_steps * args.steps + 1024)
+        profile_begin(lib, (1 << 7) | (1 << 3) | (1 << 8) | (1 << 9) | (1 << 10), 2 * 70 * args.ddpm_steps * args.steps + 1024)
     t0 = time.perf_counter()
     outs = [one_video(args.warmup + i) for i in range(args.steps)]
     local_lat = torch.cat(outs, dim=0).to(torch.float16)
@@ -422,7 +423,10 @@ def main():
                  "rows stay in registers, only weights cross LDS)", "attention.py:548-555, 580-667"),
                 ("roofline_fused_feed_forward", timed[9],
                  "geglu_mlp_kernel (level 0: norm3 + ff1 + GEGLU + ff2 + residual in ONE launch; the [T, 4C] intermediate never exists)",
-                 "attention.py:558")):
+                 "attention.py:558"),
+                ("roofline_fused_cross_attention", timed[10],
+                 "cross_block_kernel (level 0: attn1.to_out + residual + norm2 + attn2.to_q + softmax(q K^T) V over the cached text keys + "
+                 "attn2.to_out + residual in ONE launch; K / V travel in the weight stream)", "attention.py:513-534")):
             if row["launches"]:
                 tf = row["flops"] / (row["ms"] * 1e-3) / 1e12
                 bw = row["bytes"] / (row["ms"] * 1e-3) / 1e9
@@ -433,7 +437,7 @@ def main():
                                "hbm_frac": bw / PEAK_HBM_GBS}
         if os.path.isfile(pmc):
             tr = json.load(open(pmc))
-            for key in ("roofline", "roofline_temporal", "roofline_fused_temporal", "roofline_fused_feed_forward"):
+            for key in ("roofline", "roofline_temporal", "roofline_fused_temporal", "roofline_fused_feed_forward", "roofline_fused_cross_attention"):
                 if key in result and key in tr:
                     result[key]["traffic"] = tr[key]
                     result[key]["traffic_source"] = ("profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
@@ -442,15 +446,16 @@ def main():
     # ---- full per-class breakdown: one extra instrumented forward, outside the timed region
     if rank == 0 and use_prof:
         pe, ne, lat = inputs[0]
-        ctx = torch.cat([ne, pe]).half().contiguous()
+        ctx = net.cache_context(torch.cat([ne, pe]).half().contiguous())      # as the denoise loop runs it: text K / V once per prompt
         x2 = torch.cat([lat, lat]).half().contiguous()
         net(x2, 500, encoder_hidden_states=ctx)
         torch.cuda.synchronize()
-        profile_begin(lib, 0x3FF, 4096)
+        profile_begin(lib, 0x7FF, 4096)
         t1 = time.perf_counter()
         net(x2, 500, encoder_hidden_states=ctx)
         rows = profile_end(lib)
         fwd_ms = 1e3 * (time.perf_counter() - t1)
+        net.cache_context(None)
         for key, row, kernels in (("roofline_conv_class", rows[0], "igemm_patch_kernel, igemm_pp_kernel<true>, igemm_kernel<..., true, ...>, splitk_reduce_kernel"),
                                   ("roofline_linear_class", rows[1], "igemm_ppx_kernel, igemm_pp_kernel<false>, igemm_kernel<..., false, ...>, splitk_reduce_kernel")):
             if row["launches"] and row["ms"] > 0:     # whole classes, from the instrumented forward AFTER the timed region

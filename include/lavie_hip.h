@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAVIE_ABI_VERSION 5
+#define LAVIE_ABI_VERSION 6
 #define LAVIE_MAX_LEVELS 8
 
 const char* lavie_last_error(void);
@@ -106,6 +106,24 @@ int lavie_temporal_block_f16(const void* x, void* y, int B, int F, int D, int C,
                              const float* beta, const float* bo, const float* relbias, const float* rot_cos,
                              const float* rot_sin, int rot_dim, float scale, float eps, void* stream);
 
+/* Fused text cross-attention sub-block (ABI 6): with att = the output of attn1's attention core (before its to_out),
+ *     x'  = x + attn1.to_out(att)                                   (attention.py:513-522, the projection and residual)
+ *     y   = x' + attn2.to_out(attn2(norm2(x'), K, V))               (attention.py:524-534; CrossAttention :253-335)
+ * as ONE kernel: q, the attention output, norm2(x') and x' never exist in memory.  K / V = attn2.to_k / to_v of the text
+ * context are per-video constants; they travel inside the weight stream: lavie_pack_cross_block_f16 writes the weight part of
+ * an image once per model, lavie_bind_cross_block_f16 completes one image per video from kv [B * ctx_len, 2C] (k | v rows,
+ * fp16) once per context.  Rows [M, C] of video b are rows [b * rows_per_batch, (b + 1) * rows_per_batch) (rows_per_batch =
+ * frames * pixels, a multiple of 16).  y may alias x.  Built for C = 320, 8 heads, ctx_len <= 80:
+ * lavie_cross_block_image_bytes returns 0 otherwise.
+ *   wo1 / wq2 / wo2: attn1.to_out.0 / attn2.to_q / attn2.to_out.0 weights [C, C] fp16 (device); tmpl: image bytes;
+ *   img: B * image bytes (device); bo1 / bo2: the to_out biases fp32 [C]; gamma / beta: norm2 fp32 [C]; scale = dim_head^-0.5. */
+long long lavie_cross_block_image_bytes(int C, int heads);
+int lavie_pack_cross_block_f16(const void* wo1, const void* wq2, const void* wo2, int C, void* tmpl, void* stream);
+int lavie_bind_cross_block_f16(const void* tmpl, const void* kv, int B, int ctx_len, int C, void* img, void* stream);
+int lavie_cross_block_f16(const void* att, const void* x, void* y, int M, int rows_per_batch, int C, int heads, const void* img,
+                          const float* bo1, const float* gamma, const float* beta, const float* bo2, int ctx_len, float scale,
+                          float eps, void* stream);
+
 /* GroupNorm (+ optional SiLU) over channels-last rows; the "batch" is whatever shares statistics:
  *   video domain  (resnet.py:180,191; unet.py:504): NB = b,   P = f*h*w   rows per batch
  *   frame domain  (attention.py:324,369)          : NB = b*f, P = h*w
@@ -172,7 +190,7 @@ int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long lo
  * stream and fills four host arrays of LAVIE_PROFILE_CLASSES entries (launches, milliseconds,
  * algorithmic flops, algorithmic bytes — the per-launch figures are defined in DESIGN.md).
  * ---------------------------------------------------------------------------------------------- */
-#define LAVIE_PROFILE_CLASSES 10
+#define LAVIE_PROFILE_CLASSES 11
 /* Test/tuning knob for the implicit-GEMM kernel choice.  Low nibble: 0 automatic, 1 128-row kernel with the widest tile,
  * 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
  * kernel, 5 halo-patch conv kernel wherever the conv is eligible, 6 automatic without the halo-patch kernel.

@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LEVELS = 8
 
 c_void_p, c_int, c_float, c_ll, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_char_p
@@ -50,6 +50,11 @@ SIGNATURES = {
     "lavie_pack_temporal_block_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "lavie_temporal_block_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float_p, c_float_p,
                                           c_float_p, c_float_p, c_float_p, c_float_p, c_int, c_float, c_float, c_void_p]),
+    "lavie_cross_block_image_bytes": (c_ll, [c_int, c_int]),
+    "lavie_pack_cross_block_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "lavie_bind_cross_block_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lavie_cross_block_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float_p, c_float_p,
+                                       c_float_p, c_float_p, c_int, c_float, c_float, c_void_p]),
     "lavie_group_norm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float_p, c_float_p, c_float,
                                       c_int, c_float_p, c_void_p, c_void_p]),
     "lavie_group_norm_ws_floats": (c_ll, [c_int, c_int]),

@@ -81,6 +81,24 @@ int lavie_temporal_block_f16(const void* x, void* y, int B, int F, int D, int C,
                                  scale, eps, S(stream));
 }
 
+long long lavie_cross_block_image_bytes(int C, int heads) {
+    return cross_block_supported(C, heads, 1, 16) ? (long long)cross_block_image_bytes(C) : 0;
+}
+int lavie_pack_cross_block_f16(const void* wo1, const void* wq2, const void* wo2, int C, void* tmpl, void* stream) {
+    LAVIE_CHECK(wo1 && wq2 && wo2 && tmpl, "pack_cross_block: null tensor");
+    return pack_cross_block(H(wo1), H(wq2), H(wo2), C, (half_t*)tmpl, S(stream));
+}
+int lavie_bind_cross_block_f16(const void* tmpl, const void* kv, int B, int ctx_len, int C, void* img, void* stream) {
+    LAVIE_CHECK(tmpl && kv && img, "bind_cross_block: null tensor");
+    return bind_cross_block(H(tmpl), H(kv), B, ctx_len, C, (half_t*)img, S(stream));
+}
+int lavie_cross_block_f16(const void* att, const void* x, void* y, int M, int rows_per_batch, int C, int heads, const void* img,
+                          const float* bo1, const float* gamma, const float* beta, const float* bo2, int ctx_len, float scale,
+                          float eps, void* stream) {
+    return launch_cross_block(H(att), H(x), (half_t*)y, M, rows_per_batch, C, heads, H(img), bo1, gamma, beta, bo2, ctx_len, scale, eps,
+                              S(stream));
+}
+
 int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void* sc1, int SC1, const void* sc2, int SC2,
                       const void* Wp, const float* bias, const float* bias2, int ldb2, int rows_per_batch, const void* R,
                       void* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const void* zero_page,

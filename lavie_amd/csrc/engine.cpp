@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 static unsigned long g_debug_epoch = 0;
-static int g_fused_mask = ~0;          // bit 0: fused feed-forward, bit 1: fused temporal sub-block (A/B switch)
+static int g_fused_mask = ~0;          // bit 0: fused feed-forward, bit 1: fused temporal sub-block, bit 2: fused text cross-attention (A/B switch)
 void set_fused_mask(int m) { g_fused_mask = m; }
 int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
@@ -397,6 +397,16 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
         const half_t* wo = given(b + ".attn_" + tname + ".to_out.0.weight");
         WALLOC(t->tb_img, half_t, temporal_block_image_bytes(C) / sizeof(half_t));
         RUN(pack_temporal_block(wq, wk, wv, wo, C, t->tb_img, s));
+    }
+    if (!t->attn1_cross && !cfg_.vsr_blocks && cross_block_supported(C, cfg_.heads, 1, 16)) {
+        // fused text cross-attention sub-block: attn1.to_out / attn2.to_q / attn2.to_out in MFMA-fragment order; the K / V pieces
+        // of the image are bound per context (cache_context)
+        const half_t* wo1 = given(b + ".attn1.to_out.0.weight");
+        const half_t* wq2 = given(b + ".attn2.to_q.weight");
+        const half_t* wo2 = given(b + ".attn2.to_out.0.weight");
+        NEED(wo1, b + ".attn1.to_out.0.weight"); NEED(wq2, b + ".attn2.to_q.weight"); NEED(wo2, b + ".attn2.to_out.0.weight");
+        WALLOC(t->xb_tmpl, half_t, cross_block_image_bytes(C) / sizeof(half_t));
+        RUN(pack_cross_block(wo1, wq2, wo2, C, t->xb_tmpl, s));
     }
     if (geglu_mlp_supported(C)) {      // fused norm3 -> feed-forward -> residual kernel: weight image in MFMA-fragment order
         const half_t* w1 = given(b + ".ff.net.0.proj.weight");
@@ -802,6 +812,10 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     // they hold, so their producers emit none
     const bool fused_ff = t.ff_img != nullptr && !ff_first && (fused_mask() & 1);
     const bool fused_t = t.tb_img != nullptr && !ff_first && c.F == 16 && (fused_mask() & 2);
+    // attn1.to_out -> + residual -> norm2 -> attn2 -> to_out -> + residual in one kernel: needs this context's K / V image, and
+    // (it emits no row statistics) the fused temporal kernel behind it
+    const bool fused_x = t.xb_tmpl != nullptr && kv_cached && xb_bound_ && xb_img_[ti] != nullptr && fused_t && !t.attn1_cross &&
+                         (fused_mask() & 4) && cross_block_supported(C, heads, c.ctx_len, c.F * D);
     LnFold lf{nullptr, nullptr};
     RowStat rsd{nullptr, nullptr, C / igemm_rowstat_cols(T, C, C / IGEMM_BK)};
     const RowStat* rowstat = nullptr;
@@ -853,6 +867,10 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
             RUN(launch_attention(a, c.s));
         }
     }
+    if (fused_x) {
+        if (!c.dry)
+            RUN(launch_cross_block(att, tx, tx, T, c.F * D, C, heads, xb_img_[ti], t.o1.b, t.ln2.g, t.ln2.b, t.o2.b, c.ctx_len, scale, 1e-5f, c.s));
+    } else {
     RUN(linear(c, att, C, t.o1.w, t.o1.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
 
     // text cross-attention (attention.py:524-534); K/V once per video instead of once per frame (364)
@@ -873,6 +891,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         RUN(launch_attention(a, c.s));
     }
     RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, fused_t ? nullptr : rowstat));
+    }
 
     // base block order: temporal -> feed-forward (attention.py:548-560); interpolation block: feed-forward -> temporal
     // (interpolation/models/attention.py:592-604)
@@ -1166,27 +1185,32 @@ int UNet::cache_context(const half_t* ctx, int B, int ctx_len, hipStream_t strea
     LAVIE_CHECK(ws_.total_bytes() > 0, "cache_context: call lavie_unet_prepare first (split-K slabs come from the workspace)");
     const size_t rows = (size_t)B * ctx_len;
     const int X = cfg_.cross_attention_dim;
-    if (rows > kv_cache_rows_ || kv2_cache_.size() != transformers_.size()) {
+    if (rows > kv_cache_rows_ || B > kv_cache_B_ || kv2_cache_.size() != transformers_.size()) {
         // the cache lives in a block of its own: a longer context frees the old block instead of stranding it in the
         // grow-only weights arena.  Earlier forwards that read the old block are ordered before the free by the sync.
         size_t total = 0;
         auto span = [&](size_t i) { return (rows * 2 * transformers_[i].C * sizeof(half_t) + 255) & ~(size_t)255; };
-        for (size_t i = 0; i < transformers_.size(); ++i) total += span(i) * (transformers_[i].attn1_cross ? 2 : 1);
+        auto img_span = [&](size_t i) { return transformers_[i].xb_tmpl ? (size_t)B * cross_block_image_bytes(transformers_[i].C) : 0; };
+        for (size_t i = 0; i < transformers_.size(); ++i) total += span(i) * (transformers_[i].attn1_cross ? 2 : 1) + img_span(i);
         if (kv_block_) {
             LAVIE_HIP(hipStreamSynchronize(stream));
             LAVIE_HIP(hipFree(kv_block_));
             kv_block_ = nullptr;
             kv_cache_rows_ = 0;
+            kv_cache_B_ = 0;
         }
         LAVIE_HIP(hipMalloc(&kv_block_, total));
         kv2_cache_.assign(transformers_.size(), nullptr);
         kv1_cache_.assign(transformers_.size(), nullptr);
+        xb_img_.assign(transformers_.size(), nullptr);
         char* cur = (char*)kv_block_;
         for (size_t i = 0; i < transformers_.size(); ++i) {
             kv2_cache_[i] = (half_t*)cur; cur += span(i);
             if (transformers_[i].attn1_cross) { kv1_cache_[i] = (half_t*)cur; cur += span(i); }
+            if (img_span(i)) { xb_img_[i] = (half_t*)cur; cur += img_span(i); }
         }
         kv_cache_rows_ = rows;
+        kv_cache_B_ = B;
     }
     ws_.release(0);
     FwdCtx c{stream, &ws_, false, B, 1, ctx_len, nullptr};
@@ -1194,6 +1218,13 @@ int UNet::cache_context(const half_t* ctx, int B, int ctx_len, hipStream_t strea
         const TransformerW& t = transformers_[i];
         RUN(linear(c, ctx, X, t.wkv2, nullptr, 2 * t.C, X, nullptr, kv2_cache_[i], 2 * t.C, (int)rows));
         if (t.attn1_cross) RUN(linear(c, ctx, X, t.wkv1, nullptr, 2 * t.C, X, nullptr, kv1_cache_[i], 2 * t.C, (int)rows));
+    }
+    // the fused cross-attention kernel streams K / V with its weights: one image per video, written here once per context
+    xb_bound_ = false;
+    if (cross_block_supported(cfg_.block_out_channels[0], cfg_.heads, ctx_len, 16)) {
+        for (size_t i = 0; i < transformers_.size(); ++i)
+            if (xb_img_[i]) RUN(bind_cross_block(transformers_[i].xb_tmpl, kv2_cache_[i], B, ctx_len, transformers_[i].C, xb_img_[i], stream));
+        xb_bound_ = true;
     }
     kv_ctx_ = ctx;
     kv_B_ = B;

@@ -84,6 +84,7 @@ struct TransformerW {
     // row-resident fused sub-blocks (rowfuse.hip), built where the width has a kernel (level 0: C = 320)
     half_t* ff_img = nullptr; float* ff_b1img = nullptr;    // norm3 -> GEGLU feed-forward -> + residual in one kernel
     half_t* tb_img = nullptr;                               // norm_temp -> q|k|v -> temporal attention -> to_out -> + residual
+    half_t* xb_tmpl = nullptr;                              // attn1.to_out -> norm2 -> attn2 -> + residual: weight part of the image (rowfuse_cross.hip)
 };
 
 struct SamplerW { half_t* w = nullptr; float* b = nullptr; int C = 0; };
@@ -195,6 +196,10 @@ private:
     // cached text K/V (cache_context): one [B * ctx_len, 2C] buffer per transformer (attn2; attn1 on VSR cross levels)
     std::vector<half_t*> kv2_cache_, kv1_cache_;
     size_t kv_cache_rows_ = 0;                      // rows the buffers were allocated for
+    // fused text cross-attention: per transformer with a template image, [B] images = weights + this context's K / V
+    std::vector<half_t*> xb_img_;
+    int kv_cache_B_ = 0;                            // videos the image buffers were allocated for
+    bool xb_bound_ = false;                         // images hold the cached context (its length fits the kernel)
     void* kv_block_ = nullptr;                      // ONE hipMalloc'd block behind every K/V cache buffer: freed and reallocated on growth
     const half_t* kv_ctx_ = nullptr;
     int kv_B_ = 0, kv_len_ = 0;

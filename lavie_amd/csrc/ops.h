@@ -107,6 +107,16 @@ int launch_temporal_block(const half_t* x, half_t* y, int B, int F, int D, int C
                           const float* gamma, const float* beta, const float* bo, const float* relbias, const float* rot_cos,
                           const float* rot_sin, int rot_dim, float scale, float eps, hipStream_t stream);
 
+// ---- rowfuse_cross.hip: x'' = x' + to_out2(attn2(LN2(x'), K, V)), x' = x + to_out1(att), K / V of the text context streamed
+// with the weights (one image per video: pack once per model, bind once per context); y may alias x
+bool cross_block_supported(int C, int heads, int ctx_len, int rows_per_batch);
+size_t cross_block_image_bytes(int C);
+int pack_cross_block(const half_t* wo1, const half_t* wq2, const half_t* wo2, int C, half_t* tmpl, hipStream_t stream);
+int bind_cross_block(const half_t* tmpl, const half_t* kv, int B, int L, int C, half_t* img, hipStream_t stream);
+int launch_cross_block(const half_t* att, const half_t* x, half_t* y, int M, int rows_per_batch, int C, int heads, const half_t* img,
+                       const float* bo1, const float* gamma, const float* beta, const float* bo2, int L, float scale, float eps,
+                       hipStream_t stream);
+
 // host-only helper (no GPU): T5-style bucket of (query i, key j), attention.py:681-699
 void relpos_bucket_table(int F, int num_buckets, int max_distance, int* out);
 

@@ -16,7 +16,8 @@ enum KernelClass {
     KC_CONV_PATCH = 7,  // igemm_patch_kernel alone (a subset of KC_CONV3X3: the scope brackets exactly that kernel launch)
     KC_FUSED_TEMPORAL = 8,   // rowfuse.hip: norm_temp + q|k|v + temporal attention + to_out + residual in one kernel
     KC_FUSED_FF = 9,         // rowfuse.hip: norm3 + GEGLU feed-forward + residual in one kernel
-    KC_COUNT = 10
+    KC_FUSED_CROSS = 10,     // rowfuse_cross.hip: attn1.to_out + residual + norm2 + text cross-attention + to_out + residual in one kernel
+    KC_COUNT = 11
 };
 
 struct ProfileScope {

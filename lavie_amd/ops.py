@@ -126,6 +126,43 @@ def temporal_block(x, img, gamma, beta, bo, relbias, rot_cos, rot_sin, B, F, D, 
     return out
 
 
+def pack_cross_block(wo1, wq2, wo2, heads=8):
+    """attn1.to_out.0 / attn2.to_q / attn2.to_out.0 weights [C, C] (fp16, device) -> the weight part of the image of the fused
+    text cross-attention kernel (lavie_cross_block_f16).  Raises for a configuration the kernel is not built for."""
+    _chk16(wo1, wq2, wo2)
+    C = wo1.shape[0]
+    lib = _lib.load()
+    nbytes = lib.lavie_cross_block_image_bytes(C, heads)
+    if nbytes == 0:
+        raise RuntimeError(f"cross_block: C={C} heads={heads} is not built")
+    tmpl = torch.empty(nbytes // 2, dtype=torch.float16, device=wo1.device)
+    _lib.check(lib.lavie_pack_cross_block_f16(_p(wo1), _p(wq2), _p(wo2), C, _p(tmpl), _stream()), "lavie_pack_cross_block_f16")
+    return tmpl
+
+
+def bind_cross_block(tmpl, kv, B, ctx_len):
+    """Completes one image per video from kv [B * ctx_len, 2C] (attn2.to_k | to_v of the text context): once per context."""
+    _chk16(tmpl, kv)
+    C = kv.shape[1] // 2
+    if tuple(kv.shape) != (B * ctx_len, 2 * C):
+        raise RuntimeError("cross_block: kv must be [B * ctx_len, 2C]")
+    img = torch.empty(B * tmpl.numel(), dtype=torch.float16, device=tmpl.device)
+    _lib.check(_lib.load().lavie_bind_cross_block_f16(_p(tmpl), _p(kv), B, ctx_len, C, _p(img), _stream()), "lavie_bind_cross_block_f16")
+    return img
+
+
+def cross_block(att, x, img, bo1, gamma, beta, bo2, rows_per_batch, ctx_len, heads, scale, eps=1e-5, out=None):
+    """x + to_out1(att), then + to_out2(attn2(norm2(.), K, V)) in one kernel (attention.py:513-534); `out` may be x itself."""
+    _chk16(att, x, img, out)
+    _chk32(bo1, gamma, beta, bo2)
+    M, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().lavie_cross_block_f16(_p(att), _p(x), _p(out), M, rows_per_batch, C, heads, _p(img), _p(bo1), _p(gamma),
+                                                 _p(beta), _p(bo2), ctx_len, scale, eps, _stream()), "lavie_cross_block_f16")
+    return out
+
+
 def pack_conv3x3(weight, shortcut_weight=None):
     """[Cout, Cin, 3, 3] (+ optional 1x1 shortcut [Cout, Csc, 1, 1]) -> [Cout, 9*Cin (+ Csc)]."""
     _chk16(weight, shortcut_weight)

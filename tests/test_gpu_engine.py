@@ -265,6 +265,7 @@ def test_full_size_forward_vs_oracle(full):
     (>= 256 tiles), the halo-patch conv on 512-workgroup grids, 40-key-tile self-attention, multi-tile temporal
     streaming, and the fused temporal / GEGLU sub-block kernels at their production tile counts."""
     import bench
+    from lavie_amd import _lib
     from oracle import unet_fp32 as O
     net, sd = full
     pe, ne, lat = bench.synth_inputs(0, "cpu")
@@ -280,6 +281,17 @@ def test_full_size_forward_vs_oracle(full):
         assert rel_l2(got, ref) < TOL_UNET, (t, rel_l2(got, ref))
         # the two CFG halves see different text: both must match on their own
         assert rel_l2(got[0], ref[0]) < TOL_UNET and rel_l2(got[1], ref[1]) < TOL_UNET
+        # the same forward as the denoise loop runs it: text K / V cached per prompt, which is what lets the level-0 blocks take
+        # the fused text cross-attention kernel (K / V inside its weight stream) — counted, so that a silent fallback fails here
+        lib = _lib.load()
+        cc = net.cache_context(ctx.cuda())
+        bench.profile_begin(lib, 1 << 10, 64)
+        got_c = net(x.cuda(), t, encoder_hidden_states=cc).sample
+        rows = bench.profile_end(lib)
+        net.cache_context(None)
+        assert rows[10]["launches"] == 5, rows[10]            # down 0 (x2), up 3 (x3)
+        assert rel_l2(got_c, ref) < TOL_UNET, rel_l2(got_c, ref)
+        assert rel_l2(got_c[0], ref[0]) < TOL_UNET and rel_l2(got_c[1], ref[1]) < TOL_UNET
 
 
 def test_three_ddpm_steps_golden(full):

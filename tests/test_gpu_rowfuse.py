@@ -53,9 +53,9 @@ def test_geglu_mlp_rejects_unbuilt_width():
                            torch.zeros(256, 4 * 256, dtype=torch.float16, device="cuda"))
 
 
-# 24 pixels = three workgroup passes worth on a 3-workgroup grid .. no: grid = min(pixels, 256): 24 pixels -> 24 workgroups of one
-# pixel (seven idle waves each); 700 pixels -> 256 workgroups with 2-3 pixels; 5120 = the bench's level-0 shape (20 pixels per
-# workgroup: passes of 8 + 8 + 4, the weight ring restarts at every pass)
+# grid = min(pixels, 256): 24 pixels -> 24 workgroups of one pixel (seven idle waves each); 700 pixels -> 256 workgroups with
+# 2-3 pixels; 5120 = the bench's level-0 shape (20 pixels per workgroup: passes of 8 + 8 + 4, the weight ring restarts at
+# every pass)
 @pytest.mark.parametrize("B,D", [(2, 12), (1, 700), (2, 2560)])
 def test_temporal_block_fused(B, D):
     """hidden_states = self.attn_temp(self.norm_temp(hidden_states)) + hidden_states between the two rearranges of
@@ -92,3 +92,51 @@ def test_temporal_block_fused(B, D):
     assert torch.equal(got, ops.temporal_block(xd, *args))          # bit-reproducible
     ops.temporal_block(xd, *args, out=xd)                           # in place, as the engine runs it
     assert torch.equal(xd, got)
+
+
+# (videos, rows per video, context length): one pass; ragged runs with passes cut at the video boundary (163 tiles per video on
+# 256 workgroups: some workgroups own tiles of both videos); the bench's level-0 shape (20 tiles per workgroup: 8 + 8 + 4);
+# short contexts (a single key tile in use; exactly 64 keys; the full 80)
+@pytest.mark.parametrize("B,P,L", [(1, 128, 77), (2, 2608, 77), (2, 40960, 77), (3, 48, 5), (1, 1024, 64), (2, 512, 80)])
+def test_cross_block_fused(B, P, L):
+    """hidden_states = attn1(...) + hidden_states (the to_out projection and residual of attention.py:513-522), then
+    hidden_states = attn2(norm2(hidden_states), encoder_hidden_states) + hidden_states (:524-534; CrossAttention.forward /
+    _attention :253-335, K / V per video as the engine caches them) — as one kernel, against an fp32 restatement."""
+    from lavie_amd import ops
+    C, heads = 320, 8
+    dh = C // heads
+    M = B * P
+    g = gen(B * 100000 + P * 10 + L)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    x = q16(rnd(M, C) * 1.5 + 0.3 * rnd(1, C))
+    att = q16(rnd(M, C))
+    wo1, wq2, wo2 = [q16(rnd(C, C) / math.sqrt(C)) for _ in range(3)]
+    bo1, bo2 = rnd(C) * 0.2, rnd(C) * 0.2
+    gamma, beta = 1.0 + 0.2 * rnd(C), 0.1 * rnd(C)
+    kv = q16(rnd(B * L, 2 * C) * torch.cat([torch.full((C,), 1.5), torch.ones(C)]))      # sharper scores than unit keys give
+    scale = dh ** -0.5
+    x1 = x + att @ wo1.t() + bo1
+    q = (F.layer_norm(x1, (C,), gamma, beta, 1e-5) @ wq2.t()).reshape(B, P, heads, dh).permute(0, 2, 1, 3)
+    k = kv[:, :C].reshape(B, L, heads, dh).permute(0, 2, 1, 3)
+    v = kv[:, C:].reshape(B, L, heads, dh).permute(0, 2, 1, 3)
+    o = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v
+    delta2 = o.permute(0, 2, 1, 3).reshape(M, C) @ wo2.t() + bo2
+    ref = x1 + delta2
+    tmpl = ops.pack_cross_block(h16(wo1), h16(wq2), h16(wo2))
+    img = ops.bind_cross_block(tmpl, h16(kv), B, L)
+    xd, ad = h16(x), h16(att)
+    args = (img, f32(bo1), f32(gamma), f32(beta), f32(bo2), P, L, heads, scale)
+    got = ops.cross_block(ad, xd, *args)
+    assert rel_l2(got, ref) < TOL_OP
+    assert rel_l2(got.float().cpu() - x, ref - x) < 4e-3          # the residual must not hide an error in the products
+    assert torch.equal(got, ops.cross_block(ad, xd, *args))        # bit-reproducible
+    ops.cross_block(ad, xd, *args, out=xd)                         # in place, as the engine runs it
+    assert torch.equal(xd, got)
+
+
+def test_cross_block_rejects_long_context():
+    from lavie_amd import ops
+    z = torch.zeros(320, 320, dtype=torch.float16, device="cuda")
+    tmpl = ops.pack_cross_block(z, z, z)
+    with pytest.raises(RuntimeError):
+        ops.bind_cross_block(tmpl, torch.zeros(81, 640, dtype=torch.float16, device="cuda"), 1, 81)

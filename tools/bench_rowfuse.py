@@ -100,5 +100,52 @@ def main():
         print(line, flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "cross" not in sys.argv[1:]:
     main()
+
+
+def cross():
+    """fused text cross-attention sub-block vs the four launches it replaces (to_out GEMM, to_q GEMM with an explicit LayerNorm
+    left out = the LN-folded cost, attention kernel over 77 keys, to_out GEMM)."""
+    M, C, B, L, heads = 81920, 320, 2, 77, 8
+    P = M // B
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, C, generator=g).half().cuda()
+    att = torch.randn(M, C, generator=g).half().cuda()
+    wo1, wq2, wo2 = [(torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda() for _ in range(3)]
+    bo1, bo2 = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    gamma, beta = torch.ones(C).cuda(), torch.zeros(C).cuda()
+    kv = torch.randn(B * L, 2 * C, generator=g).half().cuda()
+    img = ops.bind_cross_block(ops.pack_cross_block(wo1, wq2, wo2), kv, B, L)
+    out, q, o = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    scale = 40 ** -0.5
+    k, v = kv[:, :C], kv[:, C:]
+
+    def fused():
+        ops.cross_block(att, x, img, bo1, gamma, beta, bo2, P, L, heads, scale, out=out)
+
+    def unfused():
+        ops.linear(att, wo1, bias=bo1, residual=x, out=out)
+        ops.linear(out, wq2, out=q)
+        a = ops.attention(q, k, v, B * 16, P // 16, L, heads, kv_batch_div=16, scale=scale)
+        ops.linear(a, wo2, bias=bo2, residual=out, out=o)
+
+    from lavie_amd import _lib
+    lib = _lib.load()
+    for _ in range(3):
+        fused()
+        unfused()
+    flop = 2.0 * M * C * 3 * C + 4.0 * M * L * C
+    for r in range(3):
+        lib.lavie_debug_rowfuse_variant(0)
+        t8 = timeit(fused)
+        lib.lavie_debug_rowfuse_variant(5)
+        t4 = timeit(fused)
+        lib.lavie_debug_rowfuse_variant(0)
+        tu = timeit(unfused)
+        print(f"cross round {r}: fused PF8 {t8:7.1f} us ({flop / t8 / 1e6:6.1f} TF/s)  fused PF4 {t4:7.1f} us   to_out + to_q + attention + to_out "
+              f"{tu:7.1f} us", flush=True)
+
+
+if __name__ == "__main__" and "cross" in sys.argv[1:]:
+    cross()
