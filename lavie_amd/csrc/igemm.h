@@ -88,7 +88,8 @@ int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len
 // 3 = 160x320 ping-pong kernel whenever N %% 320 == 0, 4 = automatic but never the ping-pong kernel (A/B timing),
 // 5 = halo-patch conv kernel whenever the conv is eligible, 6 = automatic but never the halo-patch kernel,
 // 7 = persistent ping-pong kernel for every eligible plain GEMM, 8 = automatic but never the persistent kernel.
-// High nibble: diagnostic ablation build of the forced kernel (results wrong).
+// High nibble: diagnostic ablation build of the forced kernel (results wrong) — except 0xC (0xC0 / 0xC5): the halo-patch kernel's
+// ping-pong K loop instead of the shipped software-pipelined one (same results; A/B timing).
 void igemm_force_tile(int mode);
 void igemm_force_splits(int s);   // 0 = automatic
 

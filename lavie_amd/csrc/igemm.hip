@@ -609,7 +609,8 @@ void igemm_force_tile(int mode) {
     g_force_tile = mode;
     igemm_ppx_ablate((mode & 0xF) == 7 ? mode >> 4 : 0);
     igemm_pp_ablate((mode & 0xF) == 3 ? mode >> 4 : 0);
-    igemm_patch_set_stamp(mode == 0x75 ? 1 : mode == 0x85 ? 2 : mode == 0x95 ? 3 : mode == 0xA5 ? 4 : mode == 0xB5 ? 5 : 0);
+    igemm_patch_set_stamp(mode == 0x75 ? 1 : mode == 0x85 ? 2 : mode == 0x95 ? 3 : mode == 0xA5 ? 4 : mode == 0xB5 ? 5 : (mode >> 4) == 0xC ? 6 : 0);
+    if ((mode >> 4) == 0xC) g_force_tile = mode & 0xF;      // 0xC0 / 0xC5: the halo-patch kernel's ping-pong K loop (A/B against the shipped software-pipelined one), kernel choice as the low nibble says
 }
 
 }  // namespace lavie

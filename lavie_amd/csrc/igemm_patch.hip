@@ -10,7 +10,15 @@
 // 26 pieces per K-tile for the same 2 x 320 x 160 x 64 flop.  Column wrap-around (x-1 at x = 0, x+1 at x = W-1) is the
 // only case the patch cannot express; those lanes read a 128-B row of zeros instead.
 //
-// Structure = igemm_pp.hip: 8 waves, wave tile 80x80 (4 waves along M, 2 along N), two groups (waves 0-3 / 4-7 = the SIMD
+// K loop, shipped build (round 3; template value STAMP = 6): software-pipelined.  Every wave interleaves the ten fragment reads
+// of the NEXT k-step (inline-asm ds_read_b128, one per two MFMAs) with the 25 in-place inline-asm MFMAs of this k-step; one
+// lgkmcnt(0) per k-step, ONE barrier per K-tile (in its middle: weight stage hand-over), weights two K-tiles ahead.
+// tools/probes/pipe_probe.hip (profiles/r03_pipe_probe.txt) priced the loop structures with the same work per K-tile: without
+// LDS-DMA both reach the MFMA ceiling of the held clock (0.83-0.86 of the 2.4 GHz peak); with the 26 LDS-DMA pieces per K-tile the
+// ping-pong skeleton drops to 0.63 and this one to 0.67, wherever the pieces come from (L2, MALL, HBM: same) — the LDS-DMA
+// writes themselves are what costs, and register-staged copies (global_load + ds_write_b128) cost more (0.53 / 0.61).
+// K loop, first build (STAMP 0-5, kept for A/B and for the stamp diagnostics) = igemm_pp.hip:
+// 8 waves, wave tile 80x80 (4 waves along M, 2 along N), two groups (waves 0-3 / 4-7 = the SIMD
 // partners) half a k-step apart, R phase (fragment reads + LDS-DMA issue) opposite the partner's M phase (25 MFMAs).
 // Group g owns output columns [80 g, 80 g + 80) and alone reads its half of the weight tile.  Per K-tile t:
 //   G0 R(t,0): W rows  0-79  of K-tile t+1 (10 pieces over 4 waves)      G1 R(t,0): W rows 80-159 of K-tile t+1
@@ -286,10 +294,14 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     advance_slab();                                 // the cursor now names the slab to prefetch
     issue_w01(t_begin, 0);
     issue_w2(t_begin, 0);
+    if constexpr (STAMP == 6) {                     // the interleaved loop keeps the weight tiles two K-tiles ahead
+        if (t_begin + 1 < t_end) {
+            issue_w01(t_begin + 1, 1);
+            issue_w2(t_begin + 1, 1);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar();
-    if (grp == 1) bar();                            // the trailing group runs one barrier behind
-
     unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     auto stamp = [&](int seg_id) {
         if constexpr (STAMP != 0) {
@@ -301,6 +313,120 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
             st_prev = tnow;
         }
     };
+    if constexpr (STAMP == 6) {
+        // ---- software-pipelined K loop (tools/probes/pipe_probe.hip: +5 % over the ping-pong skeleton with the same LDS-DMA load):
+        // every wave interleaves the NEXT k-step's ten fragment reads (inline asm, one per two MFMAs) with the 25 in-place MFMAs
+        // of this k-step; one lgkmcnt(0) per k-step, ONE barrier per K-tile, in its middle: behind it every wave's reads of this
+        // tile's weight stage are over (the stage takes tile t + 2) and the weights of tile t + 1, issued one tile ago, have landed
+        // for everyone (the reads of (t + 1, 0) start right behind the barrier).  Table reads (tap table, pixel table) ride in the
+        // same lgkmcnt window as asm reads; compiler-visible LDS reads do not occur inside the loop.
+        const unsigned lbase = (unsigned)(size_t)LDS_PTR(smem);
+        half8_t fa[2][MT], fw[2][NT];
+        tap_read(0);
+        tap_finish(0);
+        auto lds128 = [](half8_t& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory"); };
+        auto mfma_ip = [](f32x4& c, const half8_t& a, const half8_t& b) {
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        };
+        unsigned wb = lbase + w_frag;               // weight fragment base of the current K-tile's stage (k-step 0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) lds128(fa[0][mt], lbase + aaddr[mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) lds128(fw[0][nt], wb + nt * 2048);
+        int pb = 0, kt = 0, slab = slab_begin, nissue_prev = 0;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int wst = (t - t_begin) & 1;
+            const bool next_slab = slab + 1 < slab_end;
+            const bool wrap = kt == ntap - 1;
+            int piece[3];
+            unsigned pix[3] = {0u, 0u, 0u};
+            bool pissue[3];
+            int nissue = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                piece[j] = (kt * ppk + j) * 8 + wave;
+                pissue[j] = (MODE == 2 || j == 0) && j < ppk && next_slab && piece[j] < npieces;
+                nissue += pissue[j] ? 1 : 0;
+            }
+            // ---- k-step 0: MFMAs on set 0, reads of (t, 1) into set 1, then the table entries of the next tap / patch pieces
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                const unsigned wb1 = wb ^ 64u;
+                unsigned a1[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a1[mt] = lbase + (aaddr[mt] ^ 64);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        mfma_ip(acc[nt][mt], fw[0][nt], fa[0][mt]);
+                        const int m = nt * MT + mt;
+                        if (m >= 2 && m % 2 == 0 && (m - 2) / 2 < MT + NT) {
+                            const int i = (m - 2) / 2;
+                            if (i < MT) lds128(fa[1][i], a1[i]);
+                            else lds128(fw[1][i - MT], wb1 + (i - MT) * 2048);
+                        }
+                    }
+                const unsigned tapa = lbase + tap_lane + (wrap ? 0 : kt + 1) * (BM * 2);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(tv[mt]) : "v"(tapa), "n"(mt * 32) : "memory");
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (pissue[j]) asm volatile("ds_read_b32 %0, %1" : "=v"(pix[j]) : "v"(lbase + PTAB + (piece[j] * 8 + lr) * 4) : "memory");
+            }
+            // ---- middle of the K-tile
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(pix[0]), "+v"(pix[1]), "+v"(pix[2])::"memory");
+            if (wrap || nissue_prev == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (nissue_prev == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (nissue_prev == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            bar();
+            if (t + 2 < t_end) {
+                issue_w01(t + 2, wst);
+                issue_w2(t + 2, wst);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (pissue[j]) issue_patch(piece[j], pb ^ 1, (int)pix[j]);
+            nissue_prev = nissue;
+            tap_finish(wrap ? pb ^ 1 : pb);           // fragment addresses of K-tile t + 1
+            // ---- k-step 1: MFMAs on set 1, reads of (t + 1, 0) into set 0
+            {
+                const unsigned wbn = lbase + w_frag + (wst ^ 1) * W_BYTES;
+                unsigned a0[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a0[mt] = lbase + aaddr[mt];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        mfma_ip(acc[nt][mt], fw[1][nt], fa[1][mt]);
+                        const int m = nt * MT + mt;
+                        if (m >= 2 && m % 2 == 0 && (m - 2) / 2 < MT + NT) {
+                            const int i = (m - 2) / 2;
+                            if (i < MT) lds128(fa[0][i], a0[i]);
+                            else lds128(fw[0][i - MT], wbn + (i - MT) * 2048);
+                        }
+                    }
+                wb = wbn;
+            }
+            if (++kt == ntap) {
+                kt = 0;
+                pb ^= 1;
+                ++slab;
+                advance_slab();
+            }
+        }
+        // the accumulators pass through the wait states of the last MFMAs before compiler code (the epilogue) reads them
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            asm volatile("" : "+v"(acc[nt][0]), "+v"(acc[nt][1]), "+v"(acc[nt][2]), "+v"(acc[nt][3]), "+v"(acc[nt][4]));
+    } else {
+    if (grp == 1) bar();                            // the trailing group runs one barrier behind
+
     int pb = 0, kt = 0;                             // patch buffer of the current slab, tap index inside it
     int slab = slab_begin;
     // (Measured and rejected: reading a phase's fragments during the previous M phase of the same wave.  The reads then
@@ -372,7 +498,8 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         }
     }
 
-    if constexpr (STAMP != 0) {
+    }   // ping-pong loop
+    if constexpr (STAMP != 0 && STAMP != 6) {
         if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
 #pragma unroll
             for (int i = 0; i < 11; ++i) g_patch_stamps[wave * 16 + i] = st_sum[i];
@@ -392,7 +519,7 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     }
 }
 
-static int g_patch_stamp = 0;      // 0 off, 1 stamps, 2 stamps without the weight LDS-DMA (wrong results), 3 stamps without the patch LDS-DMA
+static int g_patch_stamp = 0;      // 0 shipped kernel, 1 stamps, 2 stamps without the weight LDS-DMA (wrong results), 3 stamps without the patch LDS-DMA, 6 ping-pong K loop
 void igemm_patch_set_stamp(int mode) { g_patch_stamp = mode; }
 int igemm_patch_read_stamps(unsigned long long* out) {
     LAVIE_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_patch_stamps), sizeof(unsigned long long) * 8 * 16));
@@ -440,7 +567,8 @@ static int launch_patch_nt(const IgemmParams& p, hipStream_t stream) {
     constexpr int BN = 2 * NT * 16;
     auto kern = g_patch_stamp == 1 ? igemm_patch_kernel<EPI_LINEAR, 1, NT, MODE> : g_patch_stamp == 2 ? igemm_patch_kernel<EPI_LINEAR, 2, NT, MODE>
                 : g_patch_stamp == 3 ? igemm_patch_kernel<EPI_LINEAR, 3, NT, MODE> : g_patch_stamp == 4 ? igemm_patch_kernel<EPI_LINEAR, 4, NT, MODE>
-                : g_patch_stamp == 5 ? igemm_patch_kernel<EPI_LINEAR, 5, NT, MODE> : igemm_patch_kernel<EPI_LINEAR, 0, NT, MODE>;
+                : g_patch_stamp == 5 ? igemm_patch_kernel<EPI_LINEAR, 5, NT, MODE> : g_patch_stamp == 6 ? igemm_patch_kernel<EPI_LINEAR, 0, NT, MODE>
+                : igemm_patch_kernel<EPI_LINEAR, 6, NT, MODE>;      // shipped: the software-pipelined K loop (template value 6); 6 here = the ping-pong loop
     static bool attr_set = false;
     if (!attr_set) {
         LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 0, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -449,6 +577,7 @@ static int launch_patch_nt(const IgemmParams& p, hipStream_t stream) {
         LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 3, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 4, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 5, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LAVIE_HIP(hipFuncSetAttribute((const void*)igemm_patch_kernel<EPI_LINEAR, 6, NT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set = true;
     }
     const int grid = (p.M / BM) * (p.N / BN);

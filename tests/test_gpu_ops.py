@@ -142,9 +142,11 @@ def test_conv3x3_concat_shortcut_temb(ops):
     (1, 64, 0, 160, 30, 32, 0),      # 2-D geometry is not needed here (W = 32 divides 320): still the row tiles
     (1, 64, 0, 320, 10, 512, 0),     # the VSR stage's 512-pixel rows, 160-wide column tiles
 ])
-def test_conv3x3_halo_patch_kernel(ops, n, c1, c2, cout, h, w, splits):
+@pytest.mark.parametrize("force", [5, 0xC5], ids=["pipelined-loop", "pingpong-loop"])
+def test_conv3x3_halo_patch_kernel(ops, n, c1, c2, cout, h, w, splits, force):
     """The 320x160 halo-patch conv kernel (igemm_patch.hip) forced on shapes it accepts, with bias, per-video bias
-    and residual; the same call through the default kernels must agree with it to rounding."""
+    and residual, in both of its K-loop builds (ping-pong groups; software-pipelined reads between in-place MFMAs);
+    the same call through the default kernels must agree with it to rounding."""
     from lavie_amd import _lib
     lib = _lib.load()
     g = gen(n * 7 + c1 + cout + h)
@@ -159,7 +161,7 @@ def test_conv3x3_halo_patch_kernel(ops, n, c1, c2, cout, h, w, splits):
     wp = ops.pack_conv3x3(h16(wt))
     args = dict(x2=h16(rows(x2)) if c2 else None, bias2=f32(b2), rows_per_batch=h * w, residual=h16(rows(r)))
     try:
-        lib.lavie_debug_force_tile(5)
+        lib.lavie_debug_force_tile(force)
         lib.lavie_debug_force_splits(splits)
         y = ops.conv3x3(h16(rows(x1)), wp, f32(b), n, h, w, **args)
     finally:
