@@ -20,12 +20,7 @@ namespace lavie {
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_C = 4096;
 constexpr int GN_UNROLL = 4;       // rows a thread keeps in flight
-// NB * slabs of the statistics pass.  Round 3: the apply kernel folds the slab partials itself (no finalize launch), so a
-// (batch, group) may have at most GN_MAX_SLABS_PER_NB of them; the statistics pass keeps the chip busy with fewer, fatter
-// workgroups instead (1024 threads when there are only a few batches: the 5-D GroupNorm of the resnets has NB = 2).
-constexpr int GN_MAX_SLABS = 512;
-constexpr int GN_MAX_SLABS_PER_NB = 128;
-constexpr int GN_STATS_THREADS_WIDE = 1024;
+constexpr int GN_MAX_SLABS = 2048;  // NB * slabs of the statistics pass (one finalize wave folds <= 512 partials)
 
 struct GnGeom {
     int nvec;   // (C1 + C2) / 8
@@ -34,15 +29,15 @@ struct GnGeom {
     int ty;     // row lanes = GN_THREADS / tx
 };
 
-static bool gn_geometry(int ctot, GnGeom* g, int threads = GN_THREADS) {
+static bool gn_geometry(int ctot, GnGeom* g) {
     if (ctot % 8 != 0 || ctot > GN_MAX_C) return false;
     g->nvec = ctot / 8;
     g->vpt = 1;
-    while (g->nvec / g->vpt > GN_THREADS || g->nvec % g->vpt != 0) {     // tx <= 256 for either block size: same vpt
+    while (g->nvec / g->vpt > GN_THREADS || g->nvec % g->vpt != 0) {
         if (++g->vpt > 4) return false;
     }
     g->tx = g->nvec / g->vpt;
-    g->ty = threads / g->tx;
+    g->ty = GN_THREADS / g->tx;
     return true;
 }
 
@@ -52,8 +47,8 @@ __device__ __forceinline__ const half_t* gn_src(const half_t* x1, int C1, const 
 
 // Pass 1: per-slab partial (sum, sum of squares) of every group -> partials[(nb*slabs + slab)*groups + g].
 // No atomics anywhere: fixed summation order, so a forward pass is bit-reproducible.
-template <int VPT, int THREADS>
-__global__ __launch_bounds__(THREADS) void gn_stats_kernel(const half_t* __restrict__ x1, int C1,
+template <int VPT>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const half_t* __restrict__ x1, int C1,
                                                              const half_t* __restrict__ x2, int C2, int P,
                                                              int rows_per_slab, int groups, int tx, int ty,
                                                              float* __restrict__ partials) {
@@ -110,7 +105,7 @@ __global__ __launch_bounds__(THREADS) void gn_stats_kernel(const half_t* __restr
     }
     __syncthreads();
     const int cpg = ctot / groups;
-    for (int g = tid; g < groups; g += THREADS) {
+    for (int g = tid; g < groups; g += GN_THREADS) {
         float a = 0.f, b = 0.f;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c)
             for (int y = 0; y < ty; ++y) { a += s_part[((size_t)y * ctot + c) * 2]; b += s_part[((size_t)y * ctot + c) * 2 + 1]; }
@@ -120,63 +115,60 @@ __global__ __launch_bounds__(THREADS) void gn_stats_kernel(const half_t* __restr
     }
 }
 
+// Pass 2: one wave per (batch, group): fold the slab partials in a fixed order -> (mean, rstd).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int slabs, int groups,
+                                                         int total, float inv_count, float eps,
+                                                         float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);        // nb * groups + g
+    if (idx >= total) return;
+    const int nb = idx / groups, g = idx - nb * groups;
+    // 16 partials per lane in flight (all loads, then the adds in the same ascending order): the one-load-per-iteration loop
+    // took 5.9 us for 1024 slabs — sixteen dependent L2 round trips — and ran 61 times per forward
+    float a = 0.f, b = 0.f;
+    constexpr int FU = 16;
+    for (int s0 = lane; s0 < slabs; s0 += 64 * FU) {
+        float2 v[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int sl = s0 + u * 64;
+            const int sc = sl < slabs ? sl : slabs - 1;
+            v[u] = *reinterpret_cast<const float2*>(partials + (((size_t)nb * slabs + sc) * groups + g) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            if (s0 + u * 64 < slabs) { a += v[u].x; b += v[u].y; }
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) {
+        const float mean = a * inv_count;
+        const float var = fmaxf(b * inv_count - mean * mean, 0.f);
+        stats[(size_t)idx * 2] = mean;
+        stats[(size_t)idx * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
 // y[row, :] = act((x - mean_g) * rstd_g * gamma + beta) for the slab, y is [NB*P, C1+C2] row-major.
 template <int VPT, bool SILU>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __restrict__ x1, int C1,
                                                              const half_t* __restrict__ x2, int C2, int P,
                                                              int rows_per_slab, int groups, int tx, int ty,
-                                                             const float* __restrict__ partials, int stat_slabs,
-                                                             float inv_count, float eps,
+                                                             const float* __restrict__ stats,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              half_t* __restrict__ y) {
     __shared__ float s_a[GN_MAX_C];
     __shared__ float s_b[GN_MAX_C];
-    __shared__ float s_red[GN_THREADS * 2];
-    __shared__ float s_stat[GN_THREADS * 2];       // (mean, rstd) per group (groups <= 256)
     const int ctot = C1 + C2;
     const int cpg = ctot / groups;
     const int nb = blockIdx.y;
     const int tid = threadIdx.x;
-    // ---- the statistics of this batch entry, folded from the slab partials in a fixed order by every workgroup itself (the
-    // finalize launch of rounds 1-2 is gone): thread (part, g) adds slabs part, part + nparts, ... (all its loads in flight at
-    // once), then thread g adds the nparts sums in ascending order.  <= 128 slabs x groups pairs = 32 KB from L2 per workgroup.
-    {
-        const int nparts = GN_THREADS / groups;               // groups <= 256 (checked by the launcher)
-        const int g = tid % groups, part = tid / groups;
-        float a = 0.f, b = 0.f;
-        if (part < nparts) {
-            const float* src = partials + ((size_t)nb * stat_slabs * groups + g) * 2;
-            constexpr int FU = 16;
-            for (int s0 = part; s0 < stat_slabs; s0 += nparts * FU) {
-                float2 v[FU];
-#pragma unroll
-                for (int u = 0; u < FU; ++u) {
-                    const int sl = s0 + u * nparts;
-                    v[u] = *reinterpret_cast<const float2*>(src + (size_t)(sl < stat_slabs ? sl : stat_slabs - 1) * groups * 2);
-                }
-#pragma unroll
-                for (int u = 0; u < FU; ++u)
-                    if (s0 + u * nparts < stat_slabs) { a += v[u].x; b += v[u].y; }
-            }
-            s_red[tid * 2] = a;
-            s_red[tid * 2 + 1] = b;
-        }
-        __syncthreads();
-        if (tid < groups) {
-            float sa = 0.f, sb = 0.f;
-            for (int pp = 0; pp < nparts; ++pp) { sa += s_red[(pp * groups + tid) * 2]; sb += s_red[(pp * groups + tid) * 2 + 1]; }
-            const float mean = sa * inv_count;
-            s_stat[tid * 2] = mean;
-            s_stat[tid * 2 + 1] = rsqrtf(fmaxf(sb * inv_count - mean * mean, 0.f) + eps);
-        }
-        __syncthreads();
-    }
     for (int c = tid; c < ctot; c += GN_THREADS) {
-        const int g = c / cpg;
-        const float a = s_stat[g * 2 + 1] * gamma[c];
+        const float* st = stats + ((size_t)nb * groups + c / cpg) * 2;
+        const float a = st[1] * gamma[c];
         s_a[c] = a;
-        s_b[c] = beta[c] - s_stat[g * 2] * a;
+        s_b[c] = beta[c] - st[0] * a;
     }
     __syncthreads();
     const int vx = tid % tx, vy = tid / tx;
@@ -228,51 +220,25 @@ static int gn_slabs(int P, int NB, int ty, int cap_total, int* rows_per_slab) {
     return cdiv(P, *rows_per_slab);
 }
 
-size_t gn_workspace_floats(int NB, int groups) { return ((size_t)GN_MAX_SLABS + NB) * groups * 2; }
+size_t gn_workspace_floats(int NB, int groups) { return ((size_t)GN_MAX_SLABS + NB) * groups * 2 + (size_t)NB * groups * 2; }
 
-// stats_ws layout: partials [NB][slabs][groups][2].  Two launches: slab statistics, then apply (which folds the partials).
+// stats_ws layout: [NB*groups*2 (mean, rstd)] [partials: NB*slabs*groups*2]
 int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* gamma,
                       const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream) {
-    GnGeom g, gs;
+    GnGeom g;
     const int ctot = C1 + C2;
-    // few batches (the resnets' 5-D GroupNorm: NB = 2): 1024-thread statistics workgroups, so that <= 128 slabs per batch still
-    // keep enough loads in flight to stream at the HBM rate
-    const bool wide = NB * 4 <= GN_MAX_SLABS / GN_MAX_SLABS_PER_NB * 2;        // NB <= 2
-    LAVIE_CHECK(gn_geometry(ctot, &g) && gn_geometry(ctot, &gs, wide ? GN_STATS_THREADS_WIDE : GN_THREADS),
-                "group_norm: unsupported channel count %d", ctot);
+    LAVIE_CHECK(gn_geometry(ctot, &g), "group_norm: unsupported channel count %d", ctot);
     LAVIE_CHECK(C1 % 8 == 0 && C2 % 8 == 0 && ctot % groups == 0 && groups <= GN_THREADS, "group_norm: bad channels/groups");
     ProfileScope prof(KC_GROUPNORM, stream, 0.0, 2.0 * 3.0 * (double)NB * P * ctot);   // read, read, write
-    float* partials = ws;
+    float* stats = ws;
+    float* partials = ws + (size_t)NB * groups * 2;
     int rps;
-    int cap = GN_MAX_SLABS;
-    if (cap > NB * GN_MAX_SLABS_PER_NB) cap = NB * GN_MAX_SLABS_PER_NB;
-    const int slabs = gn_slabs(P, NB, gs.ty, cap, &rps);      // NB * slabs <= cap + NB, slabs <= GN_MAX_SLABS_PER_NB
-    const size_t lds = (size_t)gs.ty * ctot * 2 * sizeof(float);
-    LAVIE_CHECK(lds <= 160 * 1024, "group_norm: statistics tile does not fit LDS (%zu B)", lds);
+    const int slabs = gn_slabs(P, NB, g.ty, GN_MAX_SLABS, &rps);      // NB * slabs <= GN_MAX_SLABS + NB
+    const size_t lds = (size_t)g.ty * ctot * 2 * sizeof(float);
     dim3 grid(slabs, NB);
-#define LAVIE_GN_STATS(V)                                                                                                        \
-    do {                                                                                                                         \
-        if (wide) {                                                                                                              \
-            auto kern = gn_stats_kernel<V, GN_STATS_THREADS_WIDE>;                                                               \
-            static bool attr_set = false;                                                                                        \
-            if (!attr_set) {                                                                                                     \
-                LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
-                attr_set = true;                                                                                                 \
-            }                                                                                                                    \
-            hipLaunchKernelGGL(kern, grid, dim3(GN_STATS_THREADS_WIDE), lds, stream, x1, C1, x2, C2, P, rps, groups, gs.tx,      \
-                               gs.ty, partials);                                                                                 \
-        } else {                                                                                                                 \
-            auto kern = gn_stats_kernel<V, GN_THREADS>;                                                                          \
-            static bool attr_set = false;                                                                                        \
-            if (!attr_set) {                                                                                                     \
-                LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
-                attr_set = true;                                                                                                 \
-            }                                                                                                                    \
-            hipLaunchKernelGGL(kern, grid, dim3(GN_THREADS), lds, stream, x1, C1, x2, C2, P, rps, groups, gs.tx, gs.ty,          \
-                               partials);                                                                                        \
-        }                                                                                                                        \
-    } while (0)
-    switch (gs.vpt) {
+#define LAVIE_GN_STATS(V) \
+    hipLaunchKernelGGL(gn_stats_kernel<V>, grid, dim3(GN_THREADS), lds, stream, x1, C1, x2, C2, P, rps, groups, g.tx, g.ty, partials)
+    switch (g.vpt) {
         case 1: LAVIE_GN_STATS(1); break;
         case 2: LAVIE_GN_STATS(2); break;
         case 3: LAVIE_GN_STATS(3); break;
@@ -280,13 +246,16 @@ int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB
     }
 #undef LAVIE_GN_STATS
     LAVIE_HIP(hipGetLastError());
-    const float inv_count = 1.0f / ((float)P * (float)(ctot / groups));
+    const int total = NB * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(total, 4)), dim3(256), 0, stream, partials, slabs, groups, total,
+                       1.0f / ((float)P * (float)(ctot / groups)), eps, stats);
+    LAVIE_HIP(hipGetLastError());
     int rps2;
     const int slabs2 = gn_slabs(P, NB, g.ty, 2048, &rps2);
     dim3 grid2(slabs2, NB);
 #define LAVIE_GN_APPLY(V, S)                                                                                        \
     hipLaunchKernelGGL((gn_apply_kernel<V, S>), grid2, dim3(GN_THREADS), 0, stream, x1, C1, x2, C2, P, rps2, groups, \
-                       g.tx, g.ty, partials, slabs, inv_count, eps, gamma, beta, y)
+                       g.tx, g.ty, stats, gamma, beta, y)
 #define LAVIE_GN_APPLY_V(V) \
     if (silu) LAVIE_GN_APPLY(V, true); else LAVIE_GN_APPLY(V, false)
     switch (g.vpt) {
