@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 static unsigned long g_debug_epoch = 0;
-static int g_fused_mask = ~0;          // bit 0: fused feed-forward, bit 1: fused temporal sub-block, bit 2: fused text cross-attention (A/B switch)
+static int g_fused_mask = ~8;         // bit 0: fused feed-forward, bit 1: fused temporal sub-block, bit 2: fused text cross-attention, bit 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (A/B switch)
 void set_fused_mask(int m) { g_fused_mask = m; }
 int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
@@ -615,7 +615,7 @@ struct RowStat {           // producer side: partials [M, slots, 2] -> (mean, rs
 
 static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const float* bias, int N, int K, const half_t* R,
                   half_t* C, int ldc, int M, int epilogue = EPI_LINEAR, const LnFold* fold = nullptr,
-                  const RowStat* rowstat = nullptr) {
+                  const RowStat* rowstat = nullptr, int ldw = 0) {
     const bool unsplit = fold != nullptr || rowstat != nullptr;
     if (c.dry) {   // plan the split-K slab so that prepare() sizes the workspace for it
         const int s = unsplit ? 1 : igemm_plan_splits(M, N, K / IGEMM_BK, epilogue);
@@ -628,7 +628,7 @@ static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const fl
     }
     IgemmParams p;
     memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = lda; p.W = W; p.ldw = K; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldc;
+    p.A = A; p.lda = lda; p.W = W; p.ldw = ldw > 0 ? ldw : K; p.C = C; p.ldc = ldc; p.bias = bias; p.R = R; p.ldr = ldc;
     p.M = M; p.N = N; p.nk = K / IGEMM_BK;
     LAVIE_CHECK(K % IGEMM_BK == 0, "linear: K=%d must be a multiple of %d", K, IGEMM_BK);
     p.splits = unsplit ? 1 : igemm_plan_splits(M, N, p.nk, epilogue);
@@ -674,7 +674,7 @@ static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsr
         sg.src = sc[i]; sg.C = scC[i]; sg.c0 = 0; sg.nchunks = scC[i] / IGEMM_BK; sg.ntaps = 1;
         nk += sg.nchunks;
     }
-    LAVIE_CHECK(nk * IGEMM_BK == ldw, "conv3x3: weight row length %d does not match gathered K %d", ldw, nk * IGEMM_BK);
+    LAVIE_CHECK(nk * IGEMM_BK <= ldw, "conv3x3: weight row length %d is shorter than the gathered K %d", ldw, nk * IGEMM_BK);
     p.nseg = ns;
     p.nk = nk;
     p.splits = igemm_plan_splits_gather(p);        // also picks the kernel: same inputs -> same choice in the dry run
@@ -686,6 +686,18 @@ static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsr
     const int rc = c.dry ? 0 : launch_igemm(p, true, EPI_LINEAR, c.s);
     c.ws->release(mark);
     return rc;
+}
+
+// Whether a plain 3x3 conv Cin -> Cout (stride 1, one source) at this geometry goes to the halo-patch kernel (the planner's rule)
+static bool conv3x3_takes_patch_kernel(int NI, int H, int W, int Cin, int Cout) {
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.Hi = p.Ho = H; p.Wi = p.Wo = W; p.stride = 1;
+    p.M = NI * H * W; p.N = Cout; p.nseg = 1;
+    p.seg[0].C = Cin; p.seg[0].nchunks = Cin / IGEMM_BK; p.seg[0].ntaps = 9;
+    p.nk = 9 * p.seg[0].nchunks;
+    p.splits = igemm_plan_splits_gather(p);
+    return igemm_patch_planned(p);
 }
 
 // (taps,1,1) temporal conv over the frame axis of token rows [(b f d), C] (IgemmParams temporal mode; 128-row kernel).
@@ -774,8 +786,23 @@ int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, cons
         const half_t* sc[2] = {x1, x2};
         const int scC[2] = {C1, C2};
         const int nsc = r.shortcut ? (x2 ? 2 : 1) : 0;
+        // The 1x1 conv_shortcut rides in conv2 as extra centre-tap K segments — which keeps conv2 off the halo-patch kernel (it
+        // takes 9-tap segments only; the ping-pong kernel stages 60 LDS-DMA pieces per K-tile against 26).  Where the planner
+        // would give the 3x3 part to the patch kernel, the shortcut can run as its own GEMM on the same packed weight rows (a
+        // column window) and come back through conv2's residual operand.  Measured (round 3, profiles/r03_ab_split_shortcut.txt):
+        // forward 21.33 -> 21.41 ms, i.e. the extra [M, Cout] round trip and launch cost more than the patch kernel gains:
+        // OFF by default (bit 3 of lavie_debug_fused_mask turns it on for A/B).
+        const bool split_sc = r.shortcut && (fused_mask() & 8) && conv3x3_takes_patch_kernel(NI, H, W, r.cout, r.cout);
+        if (split_sc) {
+            WS(scy, half_t, M * r.cout);
+            const half_t* wsc = r.w2 + 9 * r.cout;
+            if (nsc == 1) RUN(linear(c, x1, C1, wsc, nullptr, r.cout, C1, nullptr, scy, r.cout, (int)M, EPI_LINEAR, nullptr, nullptr, r.ldw2));
+            else RUN(conv3x3(c, nullptr, nullptr, 0, sc, scC, nsc, wsc, r.ldw2, nullptr, nullptr, 0, 1, nullptr, scy, NI, H, W, r.cout, 1, 0, zero_page_));
+            RUN(conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, r.w2, r.ldw2, r.b2, nullptr, 0, 1, scy, y, NI, H, W, r.cout, 1, 0, zero_page_));
+        } else {
         RUN(conv3x3(c, src, srcC, 1, sc, scC, nsc, r.w2, r.ldw2, r.b2, nullptr, 0, 1, r.shortcut ? nullptr : x1, y, NI, H, W,
                     r.cout, 1, 0, zero_page_));
+        }
     }
     c.ws->release(mark);
     return 0;

@@ -80,6 +80,8 @@ int igemm_plan_splits(int M, int N, int nk, int epilogue);
 // Same for a gathered conv whose geometry and K segments are filled in (M, N, nk, Ho, Wo, stride, ups, seg[], nseg):
 // also considers the halo-patch kernel.
 int igemm_plan_splits_gather(const IgemmParams& p);
+// whether launch_igemm would hand this gathered conv (p.splits filled in) to the halo-patch kernel
+bool igemm_patch_planned(const IgemmParams& p);
 // wave-tile width (16*NT) launch_igemm will pick for a plain, unsplit EPI_LINEAR GEMM: the row-statistics slot width
 int igemm_rowstat_cols(int M, int N, int nk);
 // partials [M, slots, 2] (sum, sum of squares over `row_len` values per row) -> out [M, 2] = (mean, rstd); fixed order

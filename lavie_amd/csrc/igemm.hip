@@ -421,6 +421,11 @@ int igemm_plan_splits_gather(const IgemmParams& p) {
     return plan_splits(p.M, p.N, p.nk, EPI_LINEAR, false);
 }
 
+bool igemm_patch_planned(const IgemmParams& p) {
+    const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);
+    return igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)));
+}
+
 int igemm_plan_splits(int M, int N, int nk, int epilogue) { return plan_splits(M, N, nk, epilogue, true); }
 
 static int plan_splits(int M, int N, int nk, int epilogue, bool plain) {
