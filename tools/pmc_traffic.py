@@ -8,7 +8,7 @@
   busy / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs), i.e. the share of SIMD cycles AT THE CLOCK THE CHIP HELD in which the
   matrix pipe was executing (GRBM_GUI_ACTIVE is summed over the 8 XCDs).
 Keys: "roofline" = igemm_patch_kernel (bench.py's dominant kernel), "conv_class" = every gathered implicit GEMM,
-"linear" = plain implicit GEMMs, "attention", "roofline_temporal", and (round 3) "roofline_fused_temporal" / "roofline_fused_feed_forward"
+"linear" = plain implicit GEMMs, "attention", "roofline_temporal", and (round 3) "roofline_fused_temporal" / "roofline_fused_feed_forward" / "roofline_fused_cross_attention"
 = the row-resident fused sub-block kernels of rowfuse.hip.
 Usage: python tools/pmc_traffic.py <dir-with-the-passes> > profiles/pmc_traffic.json"""
 import csv
@@ -36,6 +36,8 @@ def classes(name):
         out.append("roofline_fused_temporal")
     elif "geglu_mlp_kernel" in name:
         out.append("roofline_fused_feed_forward")
+    elif "cross_block_kernel" in name:
+        out.append("roofline_fused_cross_attention")
     elif "temporal_attention_kernel" in name or "temporal_stream_kernel" in name:
         out.append("roofline_temporal")
     elif "attention_kernel" in name or "attention_dma_kernel" in name:
