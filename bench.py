@@ -18,6 +18,12 @@ Extra objects on that line:
   roofline_conv_class / roofline_linear_class   whole classes (all 3x3-conv / all plain-GEMM launches), from the extra
                     instrumented forward after the timed region (an event pair costs ~11 us of stream time)
   roofline_temporal the temporal-attention core (HBM-bound): algorithmic bytes 4*tokens*C*2 per launch / duration
+  roofline_fused_*  the three row-resident level-0 kernels.  These and roofline_temporal carry launch-attached
+                    events over five forwards right after the timed region: instrumenting them inside it cost 0.75 % of `value`
+  cfg_shared_prefix the guided loop computes the layers in front of the first text cross-attention once per step (the two
+                    halves of the CFG batch are the same latents); `both_halves_computed` = the same job without that, timed
+                    after the headline region
+  batched           k prompts per UNet forward (batch 2k), timed after the headline region; never `value`
   kernel_breakdown  every kernel class, from one extra instrumented UNet forward after the timed region
   cpu_baseline      the fp32 CPU oracle (kind "port") on this host's cores: 1 warm-up + 2 timed full CFG denoise steps
                     (BASELINE.md §4), extrapolated x50
@@ -42,6 +48,10 @@ UNET_TFLOP = 16.219           # algorithmic TFLOP of one CFG forward at this con
 ATTN2_KV_TFLOP = 0.0945       # of which: the attn2 to_k / to_v projections of the 77 text tokens in the 16 blocks.
                               # cache_context() runs them ONCE per prompt, not once per step: a video executes
                               # 50 x (UNET_TFLOP - ATTN2_KV_TFLOP) + ATTN2_KV_TFLOP, and that is what the whole-path rates count
+CFG_SHARED_TFLOP = 0.3197     # of which NOT executed when the guided loop shares the layers in front of the first text cross-attention
+                              # between the two halves of the batch (identical latents, pipeline_videogen.py:666): half of conv_in
+                              # (1.9 GFLOP), down_blocks.0.resnets.0's two convs (302), and proj_in / qkv / self-attention of
+                              # down_blocks.0.attentions.0 (16.8 + 50.3 + 268.4)
 PEAK_MFMA_TFLOPS = 2500.0     # dense fp16, gfx950 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 CLASS_NAMES = ["conv3x3_igemm", "linear_igemm", "attention", "temporal_attention", "group_norm", "layer_norm", "other",
@@ -249,6 +259,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the UNet forward from a hipGraph (A/B switch; implies --no-profile: events cannot be captured)")
     ap.add_argument("--ddpm-steps", type=int, default=DDPM_STEPS, help=argparse.SUPPRESS)   # debugging only
+    ap.add_argument("--no-cfg-shared-prefix", action="store_true",
+                    help="compute both halves of the CFG batch in every layer, as the reference does (default: the layers in front of "
+                         "the first text cross-attention run once per step; the JSON line reports both rates)")
     ap.add_argument("--prompts-per-forward", type=int, default=4,
                     help="after the headline (single-prompt) measurement, also time k prompts batched into ONE UNet forward "
                          "(batch 2k; SURVEY §8e 'batched B = 2k if memory-profitable'; BASELINE.json configs[2] readiness) and "
@@ -301,6 +314,7 @@ def main():
         net.enable_graph(True)
         args.no_profile = True
     pipe = VideoGenPipeline(unet=net, scheduler=DDPMScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear"))
+    pipe.cfg_shared_prefix = not args.no_cfg_shared_prefix
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
@@ -329,7 +343,9 @@ def main():
     if use_prof:   # the dominant kernel and temporal attention only, with events attached to the kernel launches themselves
         # (hipExtLaunchKernelGGL: no extra packets).  Scope-style hipEventRecord pairs cost ~11 us of stream time each:
         # instrumenting every class that way (~270 pairs per forward) slowed the timed region by 7 % (measured).
-        profile_begin(lib, (1 << 7) | (1 << 3) | (1 << 8) | (1 << 9) | (1 << 10), 2 * 70 * args.ddpm_steps * args.steps + 1024)
+        # Only the dominant kernel is instrumented inside the timed region (19 launches per forward): with the temporal and the
+        # three fused kernels as well (45) the events cost 0.75 % of the region (measured, same box: 1101.8 vs 1093.5 ms per video).
+        profile_begin(lib, 1 << 7, 2 * 30 * args.ddpm_steps * args.steps + 1024)
     t0 = time.perf_counter()
     outs = [one_video(args.warmup + i) for i in range(args.steps)]
     local_lat = torch.cat(outs, dim=0).to(torch.float16)
@@ -371,8 +387,28 @@ def main():
                            "not the headline configuration"}
         net.prepare(2, FRAMES, LAT_H, LAT_W, CTX_LEN)
 
+    # ---- the same job with both halves of the CFG batch computed in every layer (the reference's order of work), timed after the
+    # headline region on fewer videos: reported beside `value`, never as it
+    both_halves = None
+    if pipe.cfg_shared_prefix:
+        nv = min(args.steps, 2)
+        pipe.cfg_shared_prefix = False
+        one_video(0)                     # untimed: the first video after the switch runs ~1.5 % slow (measured)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(nv):
+            one_video(args.warmup + i)
+        barrier()
+        el2 = time.perf_counter() - t2
+        pipe.cfg_shared_prefix = True
+        if world > 1:
+            tt = torch.tensor([el2], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        both_halves = {"videos_per_rank": nv, "value": nv * world / el2, "ms_per_step": 1000.0 * el2 / nv}
     total_videos = args.steps * world
-    video_tflop = (UNET_TFLOP - ATTN2_KV_TFLOP) * args.ddpm_steps + ATTN2_KV_TFLOP      # text K/V once per prompt
+    shared_tflop = CFG_SHARED_TFLOP if pipe.cfg_shared_prefix else 0.0
+    video_tflop = (UNET_TFLOP - ATTN2_KV_TFLOP - shared_tflop) * args.ddpm_steps + ATTN2_KV_TFLOP      # text K/V once per prompt
     result = {
         "metric": "video-latents/sec (16f x 320x512, 50 DDPM steps)",
         "value": total_videos / elapsed,
@@ -392,6 +428,13 @@ def main():
         "achieved_tflops_whole_path": video_tflop * total_videos / elapsed / world,
         "mfma_fraction_whole_path": video_tflop * total_videos / elapsed / world / PEAK_MFMA_TFLOPS,
         "tflop_per_video_executed": video_tflop,
+        "cfg_shared_prefix": {"enabled": bool(pipe.cfg_shared_prefix),
+                              "what": "classifier-free guidance feeds the UNet the same latents twice (pipeline_videogen.py:666); conv_in, "
+                                      "down_blocks.0.resnets.0 and GroupNorm / proj_in / self-attention of down_blocks.0.attentions.0 see no text, "
+                                      "so the guided loop computes them for one half and copies (lavie_unet_set_cfg_shared_input); outputs equal "
+                                      "the plain forward's to rounding (tests/test_gpu_engine.py)",
+                              "tflop_not_executed_per_forward": shared_tflop,
+                              "both_halves_computed": both_halves},
         "ranks_seen": dist.get_world_size() if world > 1 else 1,
         "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none (single process)",
     }
@@ -399,9 +442,29 @@ def main():
         batched["vs_single_prompt"] = batched["value"] / result["value"]
         result["batched"] = batched
 
+    def instrumented_forwards(mask, n):
+        """n UNet forwards as the guided loop runs them (cached context, shared CFG prefix), event-instrumented; class rows."""
+        pe_, ne_, lat_ = inputs[0]
+        ctx_ = net.cache_context(torch.cat([ne_, pe_]).half().contiguous())      # text K / V once per prompt, as the denoise loop
+        x2_ = torch.cat([lat_, lat_]).half().contiguous()
+        net.set_cfg_shared_input(pipe.cfg_shared_prefix)
+        net(x2_, 500, encoder_hidden_states=ctx_)
+        torch.cuda.synchronize()
+        profile_begin(lib, mask, 4096)
+        t1_ = time.perf_counter()
+        for _ in range(n):
+            net(x2_, 500, encoder_hidden_states=ctx_)
+        rows_ = profile_end(lib)
+        ms_ = 1e3 * (time.perf_counter() - t1_) / n
+        net.set_cfg_shared_input(False)
+        net.cache_context(None)
+        return rows_, ms_
+
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # filled from rocprofv3 --pmc passes, see DESIGN.md
     if rank == 0 and timed is not None:
-        temp, conv = timed[3], timed[7]
+        # the other kernels with launch-attached events: five forwards right after the timed region (same process, same clocks)
+        aux, _ = instrumented_forwards((1 << 3) | (1 << 8) | (1 << 9) | (1 << 10), 5)
+        temp, conv = aux[3], timed[7]
         if conv["launches"]:
             a = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
             result["roofline"] = {"kernel": "igemm_patch_kernel<0> (3x3 conv stride 1, halo-patch implicit GEMM, MFMA 16x16x32 f16; "
@@ -412,25 +475,27 @@ def main():
                                   "flop_per_launch": conv["flops"] / conv["launches"]}
         if temp["launches"]:
             bw = temp["bytes"] / (temp["ms"] * 1e-3) / 1e9
-            result["roofline_temporal"] = {"kernel": "temporal_stream_kernel (persistent, LDS-DMA two tiles ahead)", "bound": "hbm", "achieved": bw,
+            result["roofline_temporal"] = {"kernel": "temporal_stream_kernel (persistent, LDS-DMA two tiles ahead; levels 1-3 and mid: level 0 runs the fused kernel)",
+                                           "source": "launch-attached events, five forwards right after the timed region", "bound": "hbm", "achieved": bw,
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bw / PEAK_HBM_GBS,
                                            "traffic": None, "launches": temp["launches"],
                                            "avg_launch_us": 1e3 * temp["ms"] / temp["launches"],
                                            "bytes_per_launch": temp["bytes"] / temp["launches"]}
         for key, row, what, ref in (
-                ("roofline_fused_temporal", timed[8],
+                ("roofline_fused_temporal", aux[8],
                  "temporal_block_kernel (level 0: norm_temp + q|k|v projections + rotary / bias / softmax / PV + to_out + residual in ONE launch; "
                  "rows stay in registers, only weights cross LDS)", "attention.py:548-555, 580-667"),
-                ("roofline_fused_feed_forward", timed[9],
+                ("roofline_fused_feed_forward", aux[9],
                  "geglu_mlp_kernel (level 0: norm3 + ff1 + GEGLU + ff2 + residual in ONE launch; the [T, 4C] intermediate never exists)",
                  "attention.py:558"),
-                ("roofline_fused_cross_attention", timed[10],
+                ("roofline_fused_cross_attention", aux[10],
                  "cross_block_kernel (level 0: attn1.to_out + residual + norm2 + attn2.to_q + softmax(q K^T) V over the cached text keys + "
                  "attn2.to_out + residual in ONE launch; K / V travel in the weight stream)", "attention.py:513-534")):
             if row["launches"]:
                 tf = row["flops"] / (row["ms"] * 1e-3) / 1e12
                 bw = row["bytes"] / (row["ms"] * 1e-3) / 1e9
-                result[key] = {"kernel": what, "replaces": ref, "bound": "mfma", "achieved": tf, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                result[key] = {"kernel": what, "replaces": ref, "source": "launch-attached events, five forwards right after the timed region",
+                               "bound": "mfma", "achieved": tf, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / PEAK_MFMA_TFLOPS, "launches": row["launches"], "avg_launch_us": 1e3 * row["ms"] / row["launches"],
                                # SURVEY §8d's fused definition of the algorithmic bytes: x in + x' out + the weights once
                                "algorithmic_bytes_per_launch": row["bytes"] / row["launches"], "hbm_achieved_gbs": bw,
@@ -445,17 +510,7 @@ def main():
 
     # ---- full per-class breakdown: one extra instrumented forward, outside the timed region
     if rank == 0 and use_prof:
-        pe, ne, lat = inputs[0]
-        ctx = net.cache_context(torch.cat([ne, pe]).half().contiguous())      # as the denoise loop runs it: text K / V once per prompt
-        x2 = torch.cat([lat, lat]).half().contiguous()
-        net(x2, 500, encoder_hidden_states=ctx)
-        torch.cuda.synchronize()
-        profile_begin(lib, 0x7FF, 4096)
-        t1 = time.perf_counter()
-        net(x2, 500, encoder_hidden_states=ctx)
-        rows = profile_end(lib)
-        fwd_ms = 1e3 * (time.perf_counter() - t1)
-        net.cache_context(None)
+        rows, fwd_ms = instrumented_forwards(0x7FF, 1)
         for key, row, kernels in (("roofline_conv_class", rows[0], "igemm_patch_kernel, igemm_pp_kernel<true>, igemm_kernel<..., true, ...>, splitk_reduce_kernel"),
                                   ("roofline_linear_class", rows[1], "igemm_ppx_kernel, igemm_pp_kernel<false>, igemm_kernel<..., false, ...>, splitk_reduce_kernel")):
             if row["launches"] and row["ms"] > 0:     # whole classes, from the instrumented forward AFTER the timed region

@@ -285,6 +285,13 @@ int lavie_unet_cache_context(lavie_unet_t h, const void* ctx, int B, int ctx_len
 /* A/B switch (default on): fold every LayerNorm of the transformer blocks into the epilogues of the GEMM that
  * produces its input (row statistics) and the GEMM that consumes its output (gamma folded into the weights). */
 int lavie_unet_set_ln_fold(lavie_unet_t h, int on);
+/* Classifier-free guidance (pipeline_videogen.py:666: `torch.cat([latents] * 2)`) runs the UNet on the SAME latents twice with
+ * different text.  on = 1: the caller vouches that sample[b] == sample[b + B/2] for every b < B/2 (B even) in the forwards that
+ * follow; the layers in front of the first text cross-attention (conv_in, down_blocks.0.resnets.0, and the GroupNorm / proj_in /
+ * self-attention of down_blocks.0.attentions.0: unet.py:437-452, attention.py:369-373, 513-522) are then computed for the first
+ * half of the batch only and copied.  Outputs equal the plain forward's to rounding (a half-batch launch may pick another tile).
+ * Base UNet configuration only; ignored (plain forward) where it does not apply.  Default off. */
+int lavie_unet_set_cfg_shared_input(lavie_unet_t h, int on);
 long long lavie_unet_weight_bytes(lavie_unet_t h);
 long long lavie_unet_workspace_bytes(lavie_unet_t h);
 /* sample [B, Cin, F, H, W] fp16 (NCFHW, as the reference passes it), timesteps [B] fp32,

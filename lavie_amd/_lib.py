@@ -99,6 +99,7 @@ SIGNATURES = {
     "lavie_unet_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "lavie_unet_cache_context": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lavie_unet_set_ln_fold": (c_int, [c_void_p, c_int]),
+    "lavie_unet_set_cfg_shared_input": (c_int, [c_void_p, c_int]),
     "lavie_unet_weight_bytes": (c_ll, [c_void_p]),
     "lavie_unet_workspace_bytes": (c_ll, [c_void_p]),
     "lavie_unet_forward": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -347,6 +347,11 @@ int lavie_unet_cache_context(lavie_unet_t h, const void* ctx, int B, int ctx_len
     return h->net.cache_context(H(ctx), B, ctx_len, S(stream));
 }
 
+int lavie_unet_set_cfg_shared_input(lavie_unet_t h, int on) {
+    LAVIE_CHECK(h, "set_cfg_shared_input: null handle");
+    h->net.set_cfg_shared_input(on != 0);
+    return 0;
+}
 int lavie_unet_set_ln_fold(lavie_unet_t h, int on) {
     LAVIE_CHECK(h, "set_ln_fold: null handle");
     h->net.set_ln_fold(on != 0);

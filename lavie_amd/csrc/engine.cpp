@@ -808,7 +808,7 @@ int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, cons
     return 0;
 }
 
-int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W) {
+int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W, bool shared_prefix) {
     const int C = t.C, G = cfg_.norm_groups, heads = cfg_.heads, dh = C / heads;
     const int NI = c.B * c.F, D = H * W;
     const int T = NI * D;
@@ -826,8 +826,13 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
 
     // VSR: ResnetBlock3DCNN (3,1,1) on the block input, before the residual is taken (vsr/models/attention.py:395-400)
     if (t.tres.present) RUN(run_temporal_res(c, t.tres, x, x, C, D, nullptr, 0));
+    // shared_prefix (set_cfg_shared_input; base block only): both halves of the batch are identical up to the text
+    // cross-attention, so GroupNorm, proj_in, the qkv projection and the self-attention run on the first half (NIp frames,
+    // Tp rows) and `tx` / `att` are copied to the second
+    const int NIp = shared_prefix ? NI / 2 : NI, Tp = shared_prefix ? T / 2 : T;
+    LAVIE_CHECK(!shared_prefix || (!t.tres.present && !t.attn1_cross && c.B % 2 == 0), "transformer: shared prefix on an unsupported block");
     // per-frame GroupNorm (eps 1e-6) + 1x1 proj_in (attention.py:369-373)
-    LAUNCH(launch_group_norm(x, C, nullptr, 0, NI, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s));
+    LAUNCH(launch_group_norm(x, C, nullptr, 0, NIp, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s));
     // LayerNorm folding: the GEMM that produces the residual stream `tx` also emits per-row (sum, sum^2) partials of
     // its fp16 output, and the projection that consumes LN(tx) runs on raw `tx` with gamma folded into its weights,
     // finishing rstd * (acc - mean * s) + b' in its epilogue — no LayerNorm kernel, no normalised copy in HBM.
@@ -854,7 +859,9 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         lf.stats = rsm;
         rowstat = &rsd;
     }
-    RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, T, EPI_LINEAR, nullptr, rowstat));
+    RowStat rsd_pin = rsd;                 // the producer's slot width follows the kernel the planner picks for ITS row count
+    rsd_pin.slots = C / igemm_rowstat_cols(Tp, C, C / IGEMM_BK);
+    RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, Tp, EPI_LINEAR, nullptr, rowstat ? &rsd_pin : nullptr));
 
     if (t.attn1_cross) {
         // VSR only_cross_attention levels: attn1 attends to the text context (vsr/models/attention.py:558-561)
@@ -878,21 +885,25 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         // spatial self-attention (attention.py:513-522)
         if (fold) {
             lf.s = t.s_qkv1;
-            RUN(linear(c, tx, C, t.f_qkv1, t.b_qkv1, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
+            RUN(linear(c, tx, C, t.f_qkv1, t.b_qkv1, 3 * C, C, nullptr, wide, 3 * C, Tp, EPI_LINEAR, &lf));
         } else {
-            LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, T, C, 1e-5f, c.s));
-            RUN(linear(c, ln, C, t.wqkv1, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
+            LAUNCH(launch_layernorm(tx, t.ln1.g, t.ln1.b, ln, Tp, C, 1e-5f, c.s));
+            RUN(linear(c, ln, C, t.wqkv1, nullptr, 3 * C, C, nullptr, wide, 3 * C, Tp));
         }
         if (!c.dry) {
             AttnParams a;
             a.q = wide; a.ldq = 3 * C; a.k = wide + C; a.ldk = 3 * C; a.v = wide + 2 * C; a.ldv = 3 * C;
-            a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = D; a.heads = heads; a.dh = dh; a.kv_batch_div = 1; a.scale = scale;
+            a.o = att; a.ldo = C; a.NBq = NIp; a.Lq = D; a.Lk = D; a.heads = heads; a.dh = dh; a.kv_batch_div = 1; a.scale = scale;
             if (cfg_.sparse_causal_attn1) {      // keys/values = first frame || previous frame (interpolation attention.py:630-639)
                 a.Lk = 2 * D;
                 a.sc_frames = c.F;
             }
             RUN(launch_attention(a, c.s));
         }
+    }
+    if (shared_prefix && !c.dry) {       // the second half of the batch: the same residual stream and attention output so far
+        LAVIE_HIP(hipMemcpyAsync(tx + (size_t)Tp * C, tx, (size_t)Tp * C * sizeof(half_t), hipMemcpyDeviceToDevice, c.s));
+        LAVIE_HIP(hipMemcpyAsync(att + (size_t)Tp * C, att, (size_t)Tp * C * sizeof(half_t), hipMemcpyDeviceToDevice, c.s));
     }
     if (fused_x) {
         if (!c.dry)
@@ -1040,8 +1051,23 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
     size_t ri = 0, ti = 0, mi = 0;
     const bool tmod = cfg.vsr_temporal_modules != 0;
 
+    // Classifier-free guidance runs the UNet on the latents twice with different text: up to the first text cross-attention
+    // (conv_in, the first resnet, and GroupNorm / proj_in / self-attention of the first transformer block) the two halves of the
+    // batch are the same computation.  With set_cfg_shared_input the caller vouches for sample[b] == sample[b + B/2]; those
+    // layers then run on the first half and their outputs are copied (base UNet only: the first down block must have attention).
+    const bool shared = cfg_shared_input_ && c.B % 2 == 0 && cfg.attn_levels[0] && cfg.layers_per_block >= 1 && !tmod && !cfg.vsr_blocks &&
+                        cfg.num_class_embeds == 0 && !cfg.sparse_causal_attn1 && !transformers_[0].attn1_cross && !transformers_[0].tres.present;
+    FwdCtx ch = c;                       // the same stream / workspace / scratch, half the batch
+    if (shared) ch.B = c.B / 2;
+    auto dup_half = [&](half_t* p, size_t rows_full, int ch_count) -> int {
+        if (shared && !c.dry)
+            LAVIE_HIP(hipMemcpyAsync(p + rows_full / 2 * ch_count, p, rows_full / 2 * ch_count * sizeof(half_t), hipMemcpyDeviceToDevice, c.s));
+        return 0;
+    };
+
     WS(x0, half_t, rows(0) * C0);
-    LAUNCH(launch_conv_in(sample, conv_in_w_, conv_in_b_, x0, c.B, cfg.in_channels, c.F, Hs[0], Ws[0], C0, c.s));
+    LAUNCH(launch_conv_in(sample, conv_in_w_, conv_in_b_, x0, ch.B, cfg.in_channels, c.F, Hs[0], Ws[0], C0, c.s));
+    RUN(dup_half(x0, rows(0), C0));
     half_t* x = x0;
     int C = C0;
     skips.push_back({x, C});
@@ -1050,9 +1076,11 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
         for (int j = 0; j < cfg.layers_per_block; ++j) {
             const ResnetW& r = resnets_[ri++];
             WS(y, half_t, rows(l) * r.cout);
-            RUN(run_resnet(c, r, x, C, nullptr, 0, tproj + r.temb_off, tproj_.N, y, Hs[l], Ws[l]));
+            const bool first = shared && l == 0 && j == 0;
+            RUN(run_resnet(first ? ch : c, r, x, C, nullptr, 0, tproj + r.temb_off, tproj_.N, y, Hs[l], Ws[l]));
+            if (first) RUN(dup_half(y, rows(l), r.cout));
             x = y; C = r.cout;
-            if (cfg.attn_levels[l]) RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l]));
+            if (cfg.attn_levels[l]) RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l], first));
             skips.push_back({x, C});
         }
         if (l + 1 < L) {

@@ -128,6 +128,7 @@ public:
     long long weight_bytes() const { return (long long)weights_.total_bytes(); }
     long long workspace_bytes() const { return (long long)ws_.total_bytes(); }
     void set_ln_fold(bool on) { ln_fold_ = on; ++graph_gen_; }
+    void set_cfg_shared_input(bool on) { cfg_shared_input_ = on; ++graph_gen_; }
 
 private:
     void build_param_list();
@@ -146,7 +147,7 @@ private:
     int run(FwdCtx& c, const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out);
     int run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, const float* tproj,
                    int ld_tproj, half_t* y, int H, int W);
-    int run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W);
+    int run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W, bool shared_prefix = false);
     int run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups);
 
     struct GraphKey {
@@ -172,6 +173,9 @@ private:
     std::unordered_map<std::string, size_t> index_;
     std::vector<const half_t*> given_;
     bool finalized_ = false;
+    // the caller promises sample[b] == sample[b + B/2] (classifier-free guidance on duplicated latents): the layers in front of
+    // the first text cross-attention are computed for the first half and copied
+    bool cfg_shared_input_ = false;
     bool ln_fold_ = true;                           // LayerNorm folded into the producer / consumer GEMM epilogues
 
     DeviceArena weights_, ws_;

@@ -23,6 +23,10 @@ class StableDiffusionPipelineOutput:
 
 
 class VideoGenPipeline:
+    # With guidance the UNet input is the latents twice (line 666): let the engine compute the layers in front of the first text
+    # cross-attention once per step (UNet3DConditionModel.set_cfg_shared_input).  False = both halves computed, as the reference does.
+    cfg_shared_prefix = True
+
     def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, scheduler=None, clip_model=None,
                  clip_processor=None):
         if unet is None:
@@ -164,7 +168,12 @@ class VideoGenPipeline:
         main = torch.cuda.current_stream(dev)
         t_dev = torch.tensor(timesteps, dtype=torch.float32, device=dev)
 
+        # with guidance the two halves of model_in are the same latents (written by this loop's own step kernel): the engine may
+        # compute the layers in front of the first text cross-attention once
+        shared = do_cfg and self.cfg_shared_prefix and hasattr(self.unet, "set_cfg_shared_input")
         try:                                     # an exception in a callback or kernel must not leave the engine holding ctx
+            if shared:
+                self.unet.set_cfg_shared_input(True)
             for i, t in enumerate(timesteps):
                 eps = self.unet(model_in, t_dev[i], encoder_hidden_states=ctx).sample      # line 670
                 coeffs = sch.coefficients(t, eta) if takes_eta else sch.coefficients(t)
@@ -204,6 +213,8 @@ class VideoGenPipeline:
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t, x)
         finally:
+            if shared:
+                self.unet.set_cfg_shared_input(False)
             if hasattr(self.unet, "cache_context"):
                 self.unet.cache_context(None)
         return x

@@ -284,6 +284,14 @@ class UNet3DConditionModel(nn.Module):
         self.__dict__["_cached_ctx"] = ctx          # keeps the tensor (and so its address) alive while cached
         return ctx
 
+    def set_cfg_shared_input(self, on: bool) -> None:
+        """Classifier-free guidance feeds the UNet `torch.cat([latents] * 2)` (pipeline_videogen.py:666): with on=True the caller
+        vouches that sample[b] == sample[b + B/2] (and the timesteps likewise) in the forwards that follow, and the engine computes
+        the layers in front of the first text cross-attention once (lavie_unet_set_cfg_shared_input).  The denoise loops that
+        build the duplicated input themselves switch it on around their steps and off afterwards."""
+        handle = self._ensure_engine()
+        _lib.check(_lib.load().lavie_unet_set_cfg_shared_input(handle, 1 if on else 0), "lavie_unet_set_cfg_shared_input")
+
     def enable_graph(self, on: bool = True) -> None:
         """Replay the forward from a hipGraph (lavie_unet_forward_graph).  While on, the timestep and the output live in
         per-shape buffers owned by this module, so the captured addresses repeat from call to call: the returned tensor is

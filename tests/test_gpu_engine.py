@@ -292,6 +292,17 @@ def test_full_size_forward_vs_oracle(full):
         assert rows[10]["launches"] == 5, rows[10]            # down 0 (x2), up 3 (x3)
         assert rel_l2(got_c, ref) < TOL_UNET, rel_l2(got_c, ref)
         assert rel_l2(got_c[0], ref[0]) < TOL_UNET and rel_l2(got_c[1], ref[1]) < TOL_UNET
+        # and as the guided denoise loop runs it: both halves are the same latents, the layers in front of the first text
+        # cross-attention computed once (lavie_unet_set_cfg_shared_input)
+        try:
+            net.set_cfg_shared_input(True)
+            cc = net.cache_context(ctx.cuda())
+            got_s = net(x.cuda(), t, encoder_hidden_states=cc).sample
+        finally:
+            net.cache_context(None)
+            net.set_cfg_shared_input(False)
+        assert rel_l2(got_s, ref) < TOL_UNET, rel_l2(got_s, ref)
+        assert rel_l2(got_s[0], ref[0]) < TOL_UNET and rel_l2(got_s[1], ref[1]) < TOL_UNET
 
 
 def test_three_ddpm_steps_golden(full):
@@ -538,6 +549,50 @@ def test_pipeline_prompt_path_with_stock_text_encoder(small):
         ne = enc(Tok()("blurry").input_ids.cuda())[0]
     b = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, generator=torch.Generator().manual_seed(3), **kw).video
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_cfg_shared_input_matches_plain_forward(small):
+    """lavie_unet_set_cfg_shared_input: with the two halves of the batch holding the same latents (classifier-free guidance,
+    pipeline_videogen.py:666) the layers in front of the first text cross-attention run once; the output must equal the plain
+    forward's to rounding, for batch 2 and batch 4 ([neg0 neg1 | pos0 pos1]), cached context or not, and the switch must
+    switch off."""
+    net, _ = small
+    g = torch.Generator().manual_seed(5)
+    for nb in (2, 4):
+        lat = torch.randn(nb // 2, 4, 4, 8, 8, generator=g).half().cuda()
+        x = torch.cat([lat, lat]).contiguous()
+        ctx = torch.randn(nb, 77, 128, generator=g).half().cuda()
+        plain = net(x, 400, encoder_hidden_states=ctx).sample.clone()
+        try:
+            net.set_cfg_shared_input(True)
+            shared = net(x, 400, encoder_hidden_states=ctx).sample.clone()
+            cc = net.cache_context(ctx)
+            shared_c = net(x, 400, encoder_hidden_states=cc).sample.clone()
+            net.cache_context(None)
+        finally:
+            net.set_cfg_shared_input(False)
+        assert rel_l2(shared, plain) < 2e-3 and rel_l2(shared_c, plain) < 2e-3, (nb, rel_l2(shared, plain))
+        assert rel_l2(plain[:nb // 2], plain[nb // 2:]) > 1e-2          # the halves do differ (different text)
+        assert torch.equal(net(x, 400, encoder_hidden_states=ctx).sample, plain)      # off again: the plain path, bit for bit
+
+
+def test_pipeline_cfg_shared_prefix_matches_reference_order(small):
+    """VideoGenPipeline.cfg_shared_prefix (default on) against the same loop with both halves computed."""
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    net, _ = small
+    pipe = VideoGenPipeline(unet=net)
+    g = torch.Generator().manual_seed(9)
+    pe, ne = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    lat = torch.randn(1, 4, 16, 8, 8, generator=g)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, height=64, width=64, video_length=16, num_inference_steps=6,
+              guidance_scale=7.5, output_type="latent")
+    a = pipe(generator=torch.Generator().manual_seed(3), **kw).video.float().cpu()
+    try:
+        pipe.cfg_shared_prefix = False
+        b = pipe(generator=torch.Generator().manual_seed(3), **kw).video.float().cpu()
+    finally:
+        del pipe.cfg_shared_prefix
+    assert rel_l2(a, b) < 5e-3
 
 
 def test_context_cache_is_bit_identical_and_scoped(small):
