@@ -262,6 +262,9 @@ def main():
     ap.add_argument("--no-cfg-shared-prefix", action="store_true",
                     help="compute both halves of the CFG batch in every layer, as the reference does (default: the layers in front of "
                          "the first text cross-attention run once per step; the JSON line reports both rates)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the legs timed after the headline region (both CFG halves computed; k prompts per forward): what "
+                         "tools/collect_profiles.sh traces, so that per-kernel averages are those of the headline configuration")
     ap.add_argument("--prompts-per-forward", type=int, default=4,
                     help="after the headline (single-prompt) measurement, also time k prompts batched into ONE UNet forward "
                          "(batch 2k; SURVEY §8e 'batched B = 2k if memory-profitable'; BASELINE.json configs[2] readiness) and "
@@ -362,7 +365,7 @@ def main():
     # ---- extra: k prompts per UNet forward (batch 2k), what a rank of configs[2] (8 prompts per GPU) would run.  Separate
     # from the headline: the metric's configuration is ONE prompt at a time (configs[1]).
     batched = None
-    kpf = max(1, min(args.prompts_per_forward, 4))              # the engine takes UNet batches up to 8
+    kpf = 1 if args.headline_only else max(1, min(args.prompts_per_forward, 4))              # the engine takes UNet batches up to 8
     if kpf > 1:
         def one_batch(base):
             sets = [synth_inputs(rank + world * (base + j), device) for j in range(kpf)]
@@ -390,7 +393,7 @@ def main():
     # ---- the same job with both halves of the CFG batch computed in every layer (the reference's order of work), timed after the
     # headline region on fewer videos: reported beside `value`, never as it
     both_halves = None
-    if pipe.cfg_shared_prefix:
+    if pipe.cfg_shared_prefix and not args.headline_only:
         nv = min(args.steps, 2)
         pipe.cfg_shared_prefix = False
         one_video(0)                     # untimed: the first video after the switch runs ~1.5 % slow (measured)

@@ -551,6 +551,39 @@ def test_pipeline_prompt_path_with_stock_text_encoder(small):
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_full_width_two_prompts_per_forward_through_the_fused_kernels(full):
+    """Two prompts' CFG pairs in one UNet batch of 4 ([neg0 neg1 | pos0 pos1]) at the base width, where the level-0 blocks run the
+    row-resident fused kernels (the text cross-attention kernel streams one K / V image per batch entry and cuts its passes at
+    the video boundaries): every entry must equal the same entry computed in a batch of 2, with the context cached and the shared
+    CFG prefix on, as the guided loop runs it."""
+    from lavie_amd import _lib
+    import bench
+    net, _ = full
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(123)
+    lat = torch.randn(2, 4, 16, 8, 8, generator=g).half().cuda()
+    neg, pos = torch.randn(2, 77, 768, generator=g).half().cuda(), torch.randn(2, 77, 768, generator=g).half().cuda()
+
+    def run(x, ctx):
+        net.prepare(x.shape[0], 16, 8, 8, 77)
+        try:
+            net.set_cfg_shared_input(True)
+            cc = net.cache_context(ctx.contiguous())
+            bench.profile_begin(lib, 1 << 10, 64)
+            y = net(x.contiguous(), 321, encoder_hidden_states=cc).sample.clone()
+            rows = bench.profile_end(lib)
+            assert rows[10]["launches"] == 5, rows[10]
+            return y
+        finally:
+            net.cache_context(None)
+            net.set_cfg_shared_input(False)
+    both = run(torch.cat([lat, lat]), torch.cat([neg, pos]))
+    for j in range(2):
+        one = run(torch.cat([lat[j:j + 1]] * 2), torch.cat([neg[j:j + 1], pos[j:j + 1]]))
+        assert rel_l2(both[j], one[0]) < 2e-3 and rel_l2(both[2 + j], one[1]) < 2e-3, j
+    assert rel_l2(both[0], both[1]) > 1e-2 and rel_l2(both[0], both[2]) > 1e-2
+
+
 def test_cfg_shared_input_matches_plain_forward(small):
     """lavie_unet_set_cfg_shared_input: with the two halves of the batch holding the same latents (classifier-free guidance,
     pipeline_videogen.py:666) the layers in front of the first text cross-attention run once; the output must equal the plain
