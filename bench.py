@@ -52,6 +52,9 @@ CFG_SHARED_TFLOP = 0.3197     # of which NOT executed when the guided loop share
                               # between the two halves of the batch (identical latents, pipeline_videogen.py:666): half of conv_in
                               # (1.9 GFLOP), down_blocks.0.resnets.0's two convs (302), and proj_in / qkv / self-attention of
                               # down_blocks.0.attentions.0 (16.8 + 50.3 + 268.4)
+UPSAMPLE_PARITY_TFLOP = 0.7549  # of which NOT executed by the parity form of the three Upsample3D convs (conv3x3 of a nearest-x2 image = four
+                              # 2x2 convs on the source with pre-summed weights: 4 C instead of 9 C multiply-adds per output element):
+                              # 5/9 of 604 + 604 + 151 GFLOP
 PEAK_MFMA_TFLOPS = 2500.0     # dense fp16, gfx950 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 CLASS_NAMES = ["conv3x3_igemm", "linear_igemm", "attention", "temporal_attention", "group_norm", "layer_norm", "other",
@@ -262,6 +265,9 @@ def main():
     ap.add_argument("--no-cfg-shared-prefix", action="store_true",
                     help="compute both halves of the CFG batch in every layer, as the reference does (default: the layers in front of "
                          "the first text cross-attention run once per step; the JSON line reports both rates)")
+    ap.add_argument("--no-upsample-parity", action="store_true",
+                    help="run the three Upsample3D convs as 9-tap convs over the (virtual) upsampled image, as the reference computes "
+                         "them (default: four 2x2 convs on the source image with pre-summed weights, 2.25x fewer FLOP)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the legs timed after the headline region (both CFG halves computed; k prompts per forward): what "
                          "tools/collect_profiles.sh traces, so that per-kernel averages are those of the headline configuration")
@@ -318,6 +324,8 @@ def main():
         args.no_profile = True
     pipe = VideoGenPipeline(unet=net, scheduler=DDPMScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear"))
     pipe.cfg_shared_prefix = not args.no_cfg_shared_prefix
+    if args.no_upsample_parity:
+        _lib.check(lib.lavie_debug_fused_mask(~8 & ~16), "lavie_debug_fused_mask")
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
@@ -411,7 +419,8 @@ def main():
         both_halves = {"videos_per_rank": nv, "value": nv * world / el2, "ms_per_step": 1000.0 * el2 / nv}
     total_videos = args.steps * world
     shared_tflop = CFG_SHARED_TFLOP if pipe.cfg_shared_prefix else 0.0
-    video_tflop = (UNET_TFLOP - ATTN2_KV_TFLOP - shared_tflop) * args.ddpm_steps + ATTN2_KV_TFLOP      # text K/V once per prompt
+    parity_tflop = 0.0 if args.no_upsample_parity else UPSAMPLE_PARITY_TFLOP
+    video_tflop = (UNET_TFLOP - ATTN2_KV_TFLOP - shared_tflop - parity_tflop) * args.ddpm_steps + ATTN2_KV_TFLOP      # text K/V once per prompt
     result = {
         "metric": "video-latents/sec (16f x 320x512, 50 DDPM steps)",
         "value": total_videos / elapsed,
@@ -438,6 +447,11 @@ def main():
                                       "the plain forward's to rounding (tests/test_gpu_engine.py)",
                               "tflop_not_executed_per_forward": shared_tflop,
                               "both_halves_computed": both_halves},
+        "upsample_parity": {"enabled": not args.no_upsample_parity,
+                            "what": "Upsample3D = nearest x2 then a 3x3 conv (resnet.py:44-79): the nine taps of an output pixel fall on 2 x 2 source "
+                                    "pixels, so each output parity is a 2x2 conv on the source image with the coinciding taps' weights summed at "
+                                    "load time (one extra fp16 rounding of the summed weights; parity tests vs F.conv2d on the upsampled image)",
+                            "tflop_not_executed_per_forward": parity_tflop},
         "ranks_seen": dist.get_world_size() if world > 1 else 1,
         "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none (single process)",
     }

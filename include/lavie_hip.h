@@ -124,6 +124,19 @@ int lavie_cross_block_f16(const void* att, const void* x, void* y, int M, int ro
                           const float* bo1, const float* gamma, const float* beta, const float* bo2, int ctx_len, float scale,
                           float eps, void* stream);
 
+/* Upsample3D (ABI 6, /root/reference/base/models/resnet.py:44-79: F.interpolate(scale_factor=2, mode="nearest") then the 3x3
+ * conv): y = conv3x3(nearest_x2(x)) + bias as FOUR 2x2 convs on x, one per output parity — the nine taps of an output pixel
+ * fall on 2 x 2 source pixels, so the weights of coinciding taps are summed once at pack time (fp32 sum, one rounding) and the
+ * product needs 4 C instead of 9 C multiply-adds per output element.  Same result as lavie_conv3x3_f16(..., ups = 1) up to that
+ * rounding.  x [NI * Hi * Wi, C] rows, y [NI * 2Hi * 2Wi, C] rows.
+ *   lavie_pack_conv3x3_parity_f16: w [C, C, 3, 3] fp16 (PyTorch layout) -> out [4][C][4 C] fp16 (device);
+ *   lavie_upsample_conv3x3_supported: 1 when the geometry fits the kernel (C % 160 == 0, whole source rows per 320-pixel tile);
+ *   otherwise use lavie_conv3x3_f16 with ups = 1. */
+int lavie_pack_conv3x3_parity_f16(const void* w, void* out, int Cout, int Cin, void* stream);
+int lavie_upsample_conv3x3_supported(int NI, int Hi, int Wi, int C);
+int lavie_upsample_conv3x3_f16(const void* x, const void* wpar, const float* bias, void* y, int NI, int Hi, int Wi, int C,
+                               const void* zero_page, void* stream);
+
 /* GroupNorm (+ optional SiLU) over channels-last rows; the "batch" is whatever shares statistics:
  *   video domain  (resnet.py:180,191; unet.py:504): NB = b,   P = f*h*w   rows per batch
  *   frame domain  (attention.py:324,369)          : NB = b*f, P = h*w

@@ -55,6 +55,9 @@ SIGNATURES = {
     "lavie_bind_cross_block_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lavie_cross_block_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float_p, c_float_p,
                                        c_float_p, c_float_p, c_int, c_float, c_float, c_void_p]),
+    "lavie_pack_conv3x3_parity_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lavie_upsample_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "lavie_upsample_conv3x3_f16": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lavie_group_norm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float_p, c_float_p, c_float,
                                       c_int, c_float_p, c_void_p, c_void_p]),
     "lavie_group_norm_ws_floats": (c_ll, [c_int, c_int]),

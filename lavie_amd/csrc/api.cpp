@@ -140,6 +140,32 @@ int lavie_conv3x3_f16(const void* x1, int C1, const void* x2, int C2, const void
     return launch_igemm(p, true, EPI_LINEAR, S(stream));
 }
 
+int lavie_pack_conv3x3_parity_f16(const void* w, void* out, int Cout, int Cin, void* stream) {
+    LAVIE_CHECK(w && out && Cout > 0 && Cin > 0, "pack_conv3x3_parity: bad arguments");
+    return launch_pack_conv3x3_parity(H(w), H(out), Cout, Cin, S(stream));
+}
+int lavie_upsample_conv3x3_supported(int NI, int Hi, int Wi, int C) {
+    IgemmParams p;
+    return igemm_setup_parity_upsample(&p, nullptr, C, nullptr, nullptr, nullptr, NI, Hi, Wi, nullptr) ? 1 : 0;
+}
+int lavie_upsample_conv3x3_f16(const void* x, const void* wpar, const float* bias, void* y, int NI, int Hi, int Wi, int C,
+                               const void* zero_page, void* stream) {
+    LAVIE_CHECK(x && wpar && y && zero_page, "upsample_conv3x3: null tensor");
+    IgemmParams p;
+    LAVIE_CHECK(igemm_setup_parity_upsample(&p, H(x), C, H(wpar), bias, H(y), NI, Hi, Wi, H(zero_page)),
+                "upsample_conv3x3: NI=%d %dx%d C=%d is outside the parity kernel's geometry (lavie_upsample_conv3x3_supported)", NI, Hi, Wi, C);
+    if (p.splits > 1) {
+        const size_t need = (size_t)p.splits * p.M * p.N * sizeof(float);
+        if (need > g_slab_bytes) {
+            if (g_slab) { LAVIE_HIP(hipDeviceSynchronize()); LAVIE_HIP(hipFree(g_slab)); g_slab = nullptr; g_slab_bytes = 0; }
+            LAVIE_HIP(hipMalloc((void**)&g_slab, need));
+            g_slab_bytes = need;
+        }
+        p.slab = g_slab;
+    }
+    return launch_igemm(p, true, EPI_LINEAR, S(stream));
+}
+
 int lavie_pack_conv3x3_f16(const void* w, void* out, int Cout, int Cin, int ld_out, int col0, void* stream) {
     LAVIE_CHECK(w && out && ld_out >= col0 + 9 * Cin, "pack_conv3x3: bad arguments");
     return launch_pack_conv3x3(H(w), H(out), Cout, Cin, ld_out, col0, g_tap_major == 0, S(stream));

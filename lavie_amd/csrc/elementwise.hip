@@ -462,6 +462,37 @@ int launch_pack_conv_taps(const half_t* w, half_t* out, int Cout, int Cin, int t
     return 0;
 }
 
+// Parity weights of the 3x3 conv of a nearest-x2 upsampled image (igemm_patch.hip MODE 3): [Cout][Cin][3][3] ->
+// out[par][co][((ci / 64) * 4 + a * 2 + b) * 64 + ci % 64], par = py * 2 + px, (a, b) = the 2x2 source taps; the value is the fp32 sum
+// of the 3x3 taps (dy, dx) that land on that source pixel: parity 0: tap 0 <- {0}, tap 1 <- {1, 2}; parity 1: tap 0 <- {0, 1},
+// tap 1 <- {2} (rows and columns alike), rounded once to fp16.
+__global__ void pack_conv3x3_parity_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int Cout, int Cin) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)Cout * Cin * 4;
+    if (i >= 4 * per) return;
+    const int par = (int)(i / per);
+    const long j = i - par * per;
+    const int ci = (int)(j % Cin);
+    const int tap = (int)((j / Cin) % 4);
+    const int co = (int)(j / ((long)Cin * 4));
+    const int py = par >> 1, px = par & 1, a = tap >> 1, b = tap & 1;
+    const int dy0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), dy1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int dx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), dx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    const half_t* wk = w + ((size_t)co * Cin + ci) * 9;
+    float s = 0.f;
+    for (int dy = dy0; dy <= dy1; ++dy)
+        for (int dx = dx0; dx <= dx1; ++dx) s += (float)wk[dy * 3 + dx];
+    out[((size_t)par * Cout + co) * (4 * (size_t)Cin) + ((ci >> 6) * 4 + tap) * 64 + (ci & 63)] = (half_t)s;
+}
+
+int launch_pack_conv3x3_parity(const half_t* w, half_t* out, int Cout, int Cin, hipStream_t stream) {
+    LAVIE_CHECK(Cin % 64 == 0, "pack_conv_parity: Cin=%d must be a multiple of 64", Cin);
+    const long total = 4L * Cout * Cin * 4;
+    hipLaunchKernelGGL(pack_conv3x3_parity_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, out, Cout, Cin);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_pack_conv3x3(const half_t* w, half_t* out, int Cout, int Cin, int ld_out, int col0, bool chunked,
                         hipStream_t stream) {
     return launch_pack_conv_taps(w, out, Cout, Cin, 9, ld_out, col0, chunked, stream);

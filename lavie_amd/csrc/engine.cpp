@@ -22,7 +22,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 static unsigned long g_debug_epoch = 0;
-static int g_fused_mask = ~8;         // bit 0: fused feed-forward, bit 1: fused temporal sub-block, bit 2: fused text cross-attention, bit 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (A/B switch)
+static int g_fused_mask = ~8;         // bit 0: fused feed-forward, bit 1: fused temporal sub-block, bit 2: fused text cross-attention, bit 3: conv_shortcut as its own GEMM in front of a halo-patch conv2, bit 4: parity form of the upsample convs (A/B switch)
 void set_fused_mask(int m) { g_fused_mask = m; }
 int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
@@ -467,7 +467,7 @@ int UNet::pack_temporal_res(const std::string& prefix, int C, int taps1, Tempora
     return 0;
 }
 
-int UNet::pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s) {
+int UNet::pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s, bool up) {
     const half_t* w = given(prefix + ".weight");
     const half_t* b = given(prefix + ".bias");
     NEED(w, prefix + ".weight"); NEED(b, prefix + ".bias");
@@ -476,6 +476,10 @@ int UNet::pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStrea
     WALLOC(out->b, float, C);
     RUN(launch_pack_conv3x3(w, out->w, C, C, 9 * C, 0, true, s));
     RUN(launch_f16_to_f32(b, out->b, C, s));
+    if (up && C % 160 == 0) {          // conv(nearest_x2(x)) as four 2x2 convs on x: weights of coinciding taps summed once, here
+        WALLOC(out->wpar, half_t, (size_t)4 * C * 4 * C);
+        RUN(launch_pack_conv3x3_parity(w, out->wpar, C, C, s));
+    }
     return 0;
 }
 
@@ -533,7 +537,7 @@ int UNet::finalize(hipStream_t s) {
     for (int l = 0; l + 1 < L; ++l)
         RUN(pack_sampler("down_blocks." + std::to_string(l) + ".downsamplers.0.conv", c.block_out_channels[l], &downs_[l], s));
     for (int i = 0; i + 1 < L; ++i)
-        RUN(pack_sampler("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", c.block_out_channels[L - 1 - i], &ups_[i], s));
+        RUN(pack_sampler("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", c.block_out_channels[L - 1 - i], &ups_[i], s, /*up=*/true));
     finalized_ = true;
     return 0;
 }
@@ -997,6 +1001,21 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
 int UNet::run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups) {
     const half_t* src[1] = {x};
     const int srcC[1] = {C};
+    if (ups && stride == 1 && w.wpar && (fused_mask() & 16)) {
+        // Upsample3D (resnet.py:44-79): the 3x3 conv of the nearest-x2 image as four 2x2 convs on the source image, one per
+        // output parity, on the halo-patch kernel (igemm_patch.hip MODE 3): 4 C instead of 9 C multiply-adds per output element
+        IgemmParams p;
+        if (igemm_setup_parity_upsample(&p, x, C, w.wpar, w.b, y, c.B * c.F, Hi, Wi, zero_page_)) {
+            const size_t mark = c.ws->mark();
+            if (p.splits > 1) {
+                p.slab = (float*)c.ws->alloc((size_t)p.splits * p.M * p.N * sizeof(float));
+                if (!c.dry) LAVIE_CHECK(p.slab != nullptr, "workspace exhausted (split-K slab)");
+            }
+            const int rc = c.dry ? 0 : launch_igemm(p, true, EPI_LINEAR, c.s);
+            c.ws->release(mark);
+            return rc;
+        }
+    }
     return conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, w.w, 9 * C, w.b, nullptr, 0, 1, nullptr, y, c.B * c.F, Hi, Wi, C, stride,
                    ups, zero_page_);
 }

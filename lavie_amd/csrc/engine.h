@@ -87,7 +87,8 @@ struct TransformerW {
     half_t* xb_tmpl = nullptr;                              // attn1.to_out -> norm2 -> attn2 -> + residual: weight part of the image (rowfuse_cross.hip)
 };
 
-struct SamplerW { half_t* w = nullptr; float* b = nullptr; int C = 0; };
+struct SamplerW { half_t* w = nullptr; float* b = nullptr; int C = 0;
+                  half_t* wpar = nullptr; };    // upsamplers: the four parity weight sets [4][C][4 C] (igemm_patch.hip MODE 3)
 
 // TemporalModule3D (vsr/models/temporal_module.py:65-178): ResnetBlock3DCNN (5,1,1) -> ResnetBlock3D -> 1x1 shift conv
 struct TemporalModuleW {
@@ -141,7 +142,7 @@ private:
     int run_temporal_res(FwdCtx& c, const TemporalResW& r, const half_t* x, half_t* y, int C, int D, const float* bias2, int ldb2);
     int run_temporal_module(FwdCtx& c, const TemporalModuleW& m, const half_t* x, half_t* y, const float* tproj, int ld_tproj,
                             int H, int W);
-    int pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s);
+    int pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s, bool up = false);
     int ensure_tables(int F, hipStream_t s);
 
     int run(FwdCtx& c, const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out);

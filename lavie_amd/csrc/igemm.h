@@ -53,6 +53,8 @@ struct IgemmParams {
     // outside [0, tframes) — nn.Conv3d with kernel (T, 1, 1), padding (T/2, 0, 0) (vsr/models/resnet.py:258-259, 274).
     int tframes, tpix;
     int nseg;
+    int par_ups;          // halo-patch kernel only: parity form of the 3x3 conv of a nearest-x2 upsampled image (igemm_patch.hip MODE 3):
+                          // W = four [N][ldw] matrices (parity py * 2 + px), one 4-tap segment, M = OUTPUT rows, Hi x Wi = source grid
     int tap_major;        // diagnostic: K order tap > slab instead of slab > tap (needs weights packed to match)
     IgemmSeg seg[IGEMM_MAX_SEG];
     const half_t* zero;   // >= 128 B of zeros: source of out-of-image taps
@@ -74,6 +76,9 @@ int igemm_ppx_read_stamps(unsigned long long* out);   // diagnostic stamp build 
 bool igemm_patch_eligible(const IgemmParams& p);
 int igemm_patch_bn(int N);                        // 160 / 128 / 0: column-tile width of the halo-patch kernel for N channels
 int launch_igemm_patch(const IgemmParams& p, hipStream_t stream);
+// parity form of conv3x3(nearest_x2(x)) (igemm_patch.hip MODE 3): fills p (incl. splits; the caller sets p->slab), false = not this geometry
+bool igemm_setup_parity_upsample(IgemmParams* p, const half_t* x, int C, const half_t* wpar, const float* bias, half_t* y, int NI, int Hi,
+                                 int Wi, const half_t* zero);
 int igemm_patch_read_stamps(unsigned long long* out);   // diagnostic stamp build: [8 waves][16] cycle sums of workgroup 0
 // Split-K factor the launcher would like for this problem (1 = none); slab size = splits * M * N floats.
 int igemm_plan_splits(int M, int N, int nk, int epilogue);

@@ -552,6 +552,11 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
         }
         return 0;
     };
+    if (p.par_ups) {             // parity form of an upsample conv: the halo-patch kernel is the only one that runs it
+        LAVIE_CHECK(gather && epilogue == EPI_LINEAR && igemm_patch_eligible(p), "igemm: parity upsample conv outside the halo-patch kernel's geometry");
+        if (int rc = launch_igemm_patch(p, stream)) return rc;
+        return reduce_splits();
+    }
     if (epilogue == EPI_GEGLU) {
         LAVIE_CHECK(p.N % 128 == 0, "igemm: GEGLU needs N %% 128 == 0 (N=%d)", p.N);
         LAVIE_CHECK(!p.R && !p.bias2, "igemm: GEGLU epilogue takes no residual / per-batch bias");

@@ -29,6 +29,7 @@
 // 320 % W == 0, tile = part of one frame or whole frames, patch <= 448 rows, split-K only at slab boundaries.
 #include <hip/hip_ext.h>
 
+#include <cstring>
 #include <type_traits>
 
 #include "igemm.h"
@@ -64,6 +65,12 @@ __device__ unsigned long long g_patch_stamps[8 * 16];
 // NT = 16-column blocks per wave: 5 -> 320x160 tile (every channel count of the base model), 4 -> 320x128 (the VSR widths)
 // MODE 0: tiles of whole image rows; 1: 2-D tiles (10 rows x 32 columns); 2: temporal (T,1,1) convolution, tile = every frame of
 // 320 / F pixels (no halo at all: tap t of a row is the same pixel t - T/2 frames away, inside the tile or outside the clip)
+// MODE 3 (round 3): 3x3 conv of a nearest-x2 upsampled image (Upsample3D, resnet.py:44-79) as FOUR 2x2 convs on the source image,
+// one per output parity (py, px) = blockIdx.z: the nine taps of output pixel (2y + py, 2x + px) fall on only 2 x 2 source
+// pixels {y - 1 + py, y + py} x {x - 1 + px, x + px}, so the weights of the taps that share a source pixel are summed at pack
+// time (launch_pack_conv3x3_parity: fp32 sums, one rounding) and K shrinks from 9 C to 4 C — 2.25x fewer FLOP for the same
+// result up to that one rounding.  Tiles run over SOURCE pixels (whole source rows, as MODE 0), four K-tiles per slab, the
+// epilogue scatters a tile row to output row ((n 2H + 2y + py) 2W + 2x + px); p.M counts OUTPUT rows.
 template <int EPI, int STAMP = 0, int NT = 5, int MODE = 0>
 __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const IgemmParams p) {
     using namespace pt;
@@ -89,7 +96,8 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int split = blockIdx.y;
-    const int ntap = MODE == 2 ? __builtin_amdgcn_readfirstlane(p.seg[0].ntaps) : 9;       // K-tiles per 64-channel slab
+    const int ntap = MODE == 2 ? __builtin_amdgcn_readfirstlane(p.seg[0].ntaps) : MODE == 3 ? 4 : 9;       // K-tiles per 64-channel slab
+    const int py = MODE == 3 ? (int)(blockIdx.z >> 1) : 0, px = MODE == 3 ? (int)(blockIdx.z & 1) : 0;           // output parity
     const int nslab = p.nk / ntap;
     const int slab_begin = (int)((long)nslab * split / p.splits);
     const int slab_end = (int)((long)nslab * (split + 1) / p.splits);
@@ -97,14 +105,14 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     // patch pieces of the NEXT slab staged per K-tile and wave: the whole patch must have landed one K-tile before the slab
     // ends.  3x3: 56 pieces, one per wave over 7 of the 9 K-tiles; temporal: 40 pieces (320 rows), two (T = 5) or three (T = 3)
     const int npieces = MODE == 2 ? BM / 8 : PATCH_PIECES;
-    const int ppk = MODE == 2 ? (ntap >= 5 ? 2 : 3) : 1;
+    const int ppk = MODE == 2 ? (ntap >= 5 ? 2 : 3) : MODE == 3 ? 3 : 1;
 
     const int lr = lane >> 3;
     const int kofs = ((lane & 7) ^ lr) * 8;         // source K offset (halfs) after the slot swizzle
     auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
     // ---- tile geometry: 320 pixels = `rows_seg` image rows of each of `nf` frame segments, or (t2) 10 rows x 32 columns
-    const int Wd = MODE == 2 ? BM : p.Wo, Hd = MODE == 2 ? 1 : p.Ho, HW = Hd * Wd;      // (unused in temporal mode)
+    const int Wd = MODE == 2 ? BM : MODE == 3 ? p.Wi : p.Wo, Hd = MODE == 2 ? 1 : MODE == 3 ? p.Hi : p.Ho, HW = Hd * Wd;      // (unused in temporal mode)
     constexpr bool t2 = MODE == 1;                  // the launcher instantiates MODE 1 exactly when BM % Wd != 0
     constexpr bool tmode = MODE == 2;
     const int seg_px = HW >= BM ? BM : HW;          // pixels of one frame segment inside the tile
@@ -156,6 +164,12 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
                 u = (tap < ntap && (unsigned)ff < (unsigned)tF) ? ff * PX + (r - (r / PX) * PX) : PATCH_ROWS;
             } else if (t2) {                                // halo columns are part of the patch: no wrap-around case
                 u = (r / T2_W + dy) * T2_PW + (r % T2_W) + dx;
+            } else if (MODE == 3) {                         // 2x2 taps (a, b) of output parity (py, px): source pixel (y - 1 + py + a, x - 1 + px + b)
+                const int a = tap >> 1, b = tap & 1, dyy = a - 1 + py, dxx = b - 1 + px;
+                const int f = r / seg_px, rr = r - f * seg_px;
+                const int x = rr % Wd;
+                const bool bad = tap >= 4 || (unsigned)(x + dxx) >= (unsigned)Wd;
+                u = bad ? PATCH_ROWS : f * PF + Wd + rr + dyy * Wd + dxx;
             } else {
                 const int f = r / seg_px, rr = r - f * seg_px;
                 const int x = rr % Wd;
@@ -221,7 +235,8 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
     // ---- weight pieces of this wave: rows 80 grp + (q + 4 j) * 8, j = 0..2 (j = 2 only for q < 2: 10 pieces per half)
     const half_t* wptr[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) wptr[j] = p.W + (size_t)(n0 + grp * (NT * 16) + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
+    for (int j = 0; j < 3; ++j)
+        wptr[j] = p.W + (MODE == 3 ? (size_t)blockIdx.z * p.N * p.ldw : (size_t)0) + (size_t)(n0 + grp * (NT * 16) + (q + 4 * j) * 8 + lr) * p.ldw + kofs;
     const bool w3 = NT == 5 && q < 2;               // 80 rows per group = 10 pieces; 64 rows = 8 pieces: two per wave
     auto issue_w01 = [&](int t, int wst) {
         char* base = smem + W_BASE + wst * W_BYTES + grp * (NT * 16 * 128);
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 piece[j] = (kt * ppk + j) * 8 + wave;
-                pissue[j] = (MODE == 2 || j == 0) && j < ppk && next_slab && piece[j] < npieces;
+                pissue[j] = (MODE >= 2 || j == 0) && j < ppk && next_slab && piece[j] < npieces;
                 nissue += pissue[j] ? 1 : 0;
             }
             // ---- k-step 0: MFMAs on set 0, reads of (t, 1) into set 1, then the table entries of the next tap / patch pieces
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             piece[j] = (kt * ppk + j) * 8 + wave;
-            pissue[j] = (MODE == 2 || j == 0) && j < ppk && next_slab && piece[j] < npieces;
+            pissue[j] = (MODE >= 2 || j == 0) && j < ppk && next_slab && piece[j] < npieces;
             nissue += pissue[j] ? 1 : 0;
         }
         // ---- R(t, 0): fragments, two weight pieces of K-tile t+1, the pixels of this K-tile's patch pieces
@@ -506,7 +521,13 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
             g_patch_stamps[wave * 16 + 11] = (unsigned long long)(t_end - t_begin);
         }
     }
-    if constexpr (tmode) {
+    if constexpr (MODE == 3) {         // scatter: source pixel (n, y, x) of this lane -> output pixel (n, 2y + py, 2x + px)
+        igemm_epilogue_rows<MT, NT, EPI>(p, acc, [&](int mt) {
+            const int m = m0 + wm * (MT * 16) + mt * 16 + (lane & 15);
+            const int n = m / HW, rem = m - n * HW, y = rem / Wd, x = rem - y * Wd;
+            return ((n * 2 * Hd + 2 * y + py) * 2 * Wd) + 2 * x + px;
+        }, n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);
+    } else if constexpr (tmode) {
         igemm_epilogue_rows<MT, NT, EPI>(p, acc, [&](int mt) { return trow(wm * (MT * 16) + mt * 16 + (lane & 15)); },
                                          n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);
     } else if constexpr (t2) {       // slice mt of wave row wm = 16 pixels of image row ty0 + (5 wm + mt) / 2, columns tx0 + 16 ((5 wm + mt) & 1) ..
@@ -541,8 +562,40 @@ static bool patch_temporal_ok(const IgemmParams& p) {
     return p.splits >= 1 && p.splits <= p.nk / T;
 }
 
+// Parity form of the conv of a nearest-x2 upsampled image (MODE 3): one 4-tap segment, whole source rows per tile, 160-wide tiles
+static bool patch_parity_ok(const IgemmParams& p) {
+    if (p.stride != 1 || p.nseg != 1 || p.seg[0].ntaps != 4 || p.tframes > 0) return false;
+    if (igemm_patch_bn(p.N) != 160 || p.M % 4 != 0 || (p.M / 4) % pt::BM != 0 || p.nk % 4 != 0) return false;
+    const int W = p.Wi, HW = p.Hi * p.Wi;
+    if (p.Ho != 2 * p.Hi || p.Wo != 2 * p.Wi || pt::BM % W != 0 || W % 8 != 0) return false;
+    if (!(HW % pt::BM == 0 || pt::BM % HW == 0)) return false;
+    const int seg_px = HW >= pt::BM ? pt::BM : HW;
+    if ((pt::BM / seg_px) * (seg_px / W + 2) * W > pt::PATCH_ROWS) return false;
+    return p.splits >= 1 && p.splits <= p.nk / 4;
+}
+
+// Fills `p` for y = conv3x3(nearest_x2(x)) + bias in parity form (x [NI, Hi, Wi, C] rows, y [NI, 2Hi, 2Wi, C] rows, wpar from
+// launch_pack_conv3x3_parity) including the split-K factor (the caller provides p->slab when splits > 1); false = the halo-patch
+// kernel's geometry does not hold and the caller runs the 9-tap gather conv with ups = 1 instead.
+bool igemm_setup_parity_upsample(IgemmParams* p, const half_t* x, int C, const half_t* wpar, const float* bias, half_t* y, int NI, int Hi,
+                                 int Wi, const half_t* zero) {
+    memset(p, 0, sizeof(*p));
+    if (C % IGEMM_BK != 0) return false;
+    p->W = wpar; p->ldw = 4 * C; p->C = y; p->ldc = C; p->bias = bias; p->rows_per_batch = 1; p->ldr = C;
+    p->Hi = Hi; p->Wi = Wi; p->Ho = 2 * Hi; p->Wo = 2 * Wi; p->stride = 1; p->par_ups = 1;
+    p->M = NI * p->Ho * p->Wo; p->N = C; p->zero = zero;
+    p->nseg = 1;
+    p->seg[0].src = x; p->seg[0].C = C; p->seg[0].c0 = 0; p->seg[0].nchunks = C / IGEMM_BK; p->seg[0].ntaps = 4;
+    p->nk = 4 * p->seg[0].nchunks;
+    // one workgroup per CU and 85 % of a round as everywhere in the family; split-K over whole slabs when the grid is short
+    const long wgs = (long)(p->M / 4 / pt::BM) * (C / 160) * 4;
+    p->splits = wgs >= 218 ? 1 : (2 * wgs >= 218 && p->seg[0].nchunks >= 10) ? 2 : (p->seg[0].nchunks >= 20 ? 4 : 1);
+    return patch_parity_ok(*p);
+}
+
 // Whether the halo-patch kernel can run this conv (geometry only; the caller decides on grid fill and split-K).
 bool igemm_patch_eligible(const IgemmParams& p) {
+    if (p.par_ups) return patch_parity_ok(p);
     if (p.stride != 1 || p.ups != 0) return false;
     if (p.tframes > 0) return patch_temporal_ok(p);
     if (igemm_patch_bn(p.N) == 0 || p.M % pt::BM != 0 || p.nk % 9 != 0) return false;
@@ -559,6 +612,25 @@ bool igemm_patch_eligible(const IgemmParams& p) {
         if (patch_rows > pt::PATCH_ROWS || patch_rows >= (1 << 16)) return false;
     }
     return p.splits >= 1 && p.splits <= p.nk / 9;
+}
+
+// MODE 3 (parity form of the upsample conv): shipped K loop only, four parities on gridDim.z
+static int launch_patch_parity(const IgemmParams& p, hipStream_t stream) {
+    using namespace pt;
+    auto kern = igemm_patch_kernel<EPI_LINEAR, 6, 5, 3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    const int grid = (p.M / 4 / BM) * (p.N / 160);
+    const double K = (double)p.nk * IGEMM_BK;
+    // executed work: K = 4 Cin per output pixel; bytes: source once per parity pass / 4 taps, the four weight sets, the output
+    ProfileScope prof(KC_CONV_PATCH, stream, 2.0 * p.M * p.N * K, 2.0 * ((double)p.M * K / 4.0 / 4.0 + 4.0 * p.N * K + (double)p.M * p.N), /*kernel_events=*/true);
+    if (prof.active()) hipExtLaunchKernelGGL(kern, dim3(grid, p.splits, 4), dim3(THREADS), LDS_BYTES, stream, prof.start(), prof.stop(), 0, p);
+    else hipLaunchKernelGGL(kern, dim3(grid, p.splits, 4), dim3(THREADS), LDS_BYTES, stream, p);
+    LAVIE_HIP(hipGetLastError());
+    return 0;
 }
 
 template <int NT, int MODE>
@@ -593,6 +665,7 @@ static int launch_patch_nt(const IgemmParams& p, hipStream_t stream) {
 // Launches the halo-patch conv kernel (EPI_LINEAR; the caller runs the split-K reduce).
 int launch_igemm_patch(const IgemmParams& p, hipStream_t stream) {
     LAVIE_CHECK(igemm_patch_eligible(p), "igemm_patch: conv geometry not supported by the halo-patch kernel");
+    if (p.par_ups) return launch_patch_parity(p, stream);
     if (p.tframes > 0) return launch_patch_nt<4, 2>(p, stream);
     const bool t2 = pt::BM % p.Wo != 0;
     if (igemm_patch_bn(p.N) == 160) return t2 ? launch_patch_nt<5, 1>(p, stream) : launch_patch_nt<5, 0>(p, stream);

@@ -73,6 +73,7 @@ int launch_fill_relpos_bias(const half_t* emb, const int* buckets, float* out, i
 // chunked = true: K order (64-channel slab, tap, channel) for the implicit GEMM; false: (tap, channel) for conv_out
 int launch_pack_conv3x3(const half_t* w, half_t* out, int Cout, int Cin, int ld_out, int col0, bool chunked,
                         hipStream_t stream);
+int launch_pack_conv3x3_parity(const half_t* w, half_t* out, int Cout, int Cin, hipStream_t stream);   // [4][Cout][4 Cin], see elementwise.hip
 int launch_pack_conv_taps(const half_t* w, half_t* out, int Cout, int Cin, int taps, int ld_out, int col0, bool chunked,
                           hipStream_t stream);
 int launch_copy_rows(const half_t* src, int ld_src, half_t* dst, int ld_dst, int rows, int cols, int col0,

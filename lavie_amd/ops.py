@@ -204,6 +204,27 @@ def conv3x3(x1, wp, bias, ni, hi, wi, x2=None, sc1=None, sc2=None, bias2=None, r
     return y
 
 
+def pack_conv3x3_parity(weight):
+    """[C, C, 3, 3] (fp16, device) -> the four parity weight sets [4, C, 4C] of the upsample conv (lavie_upsample_conv3x3_f16)."""
+    _chk16(weight)
+    cout, cin = weight.shape[0], weight.shape[1]
+    out = torch.empty(4, cout, 4 * cin, dtype=torch.float16, device=weight.device)
+    _lib.check(_lib.load().lavie_pack_conv3x3_parity_f16(_p(weight.contiguous()), _p(out), cout, cin, _stream()), "lavie_pack_conv3x3_parity_f16")
+    return out
+
+
+def upsample_conv3x3(x, wpar, bias, ni, hi, wi):
+    """conv3x3(nearest_x2(x)) + bias (Upsample3D, resnet.py:44-79) in parity form: x [ni*hi*wi, C] rows -> [ni*2hi*2wi, C] rows.
+    Raises where the kernel's geometry does not hold (use conv3x3(..., ups=1) there)."""
+    _chk16(x, wpar)
+    _chk32(bias)
+    c = x.shape[1]
+    y = torch.empty(ni * 4 * hi * wi, c, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().lavie_upsample_conv3x3_f16(_p(x), _p(wpar), _p(bias), _p(y), ni, hi, wi, c, _p(_zero_page(x.device)), _stream()),
+               "lavie_upsample_conv3x3_f16")
+    return y
+
+
 def pack_temporal_conv(weight):
     """nn.Conv3d weight [Cout, Cin, T, 1, 1] (T = 3 or 5) -> [Cout, T*Cin] in the implicit GEMM's K order."""
     _chk16(weight)

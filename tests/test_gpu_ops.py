@@ -170,6 +170,46 @@ def test_conv3x3_halo_patch_kernel(ops, n, c1, c2, cout, h, w, splits, force):
     assert rel_l2(unrows(y.float().cpu(), n, h, w), ref) < TOL_OP
 
 
+# (frames, channels, source h, w): several frames per 320-pixel tile with split-K 2 (8 x 5x8: the deepest upsampler's geometry);
+# two frames per tile (10x16); one frame = two tiles (20x32, the level-1 -> level-0 upsampler of the bench); four slabs, one
+# frame per tile with ragged image borders everywhere (10x32); 1280 channels (20 slabs: split-K 4 on a short grid)
+@pytest.mark.parametrize("n,c,h,w", [(32, 320, 5, 8), (8, 320, 10, 16), (4, 640, 20, 32), (3, 160 * 2, 10, 32), (8, 1280, 5, 8)])
+def test_upsample_conv3x3_parity_form(ops, n, c, h, w):
+    """Upsample3D (resnet.py:44-79): conv3x3(nearest_x2(x)) + bias as four 2x2 convs on x (igemm_patch.hip MODE 3, weights of
+    coinciding taps summed at pack time) against F.conv2d on the materialised upsampled image, and against the engine's 9-tap
+    gather conv with ups = 1."""
+    from lavie_amd import _lib
+    lib = _lib.load()
+    assert lib.lavie_upsample_conv3x3_supported(n, h, w, c) == 1
+    g = gen(n * 31 + c + h)
+    x = q16(torch.randn(n, c, h, w, generator=g))
+    wt = q16(torch.randn(c, c, 3, 3, generator=g) / math.sqrt(9 * c))
+    b = torch.randn(c, generator=g)
+    ref = conv_ref(x, wt, b, 1, 1)
+    y = ops.upsample_conv3x3(h16(rows(x)), ops.pack_conv3x3_parity(h16(wt)), f32(b), n, h, w)
+    got = unrows(y.float().cpu(), n, 2 * h, 2 * w)
+    assert rel_l2(got, ref) < TOL_OP
+    # every output parity and the image border on its own (a wrong tap sum or scatter shows up in one of them only)
+    for py in (0, 1):
+        for px in (0, 1):
+            assert rel_l2(got[:, :, py::2, px::2], ref[:, :, py::2, px::2]) < TOL_OP, (py, px)
+    border = torch.ones(2 * h, 2 * w, dtype=torch.bool)
+    border[1:-1, 1:-1] = False
+    assert rel_l2(got[:, :, border], ref[:, :, border]) < TOL_OP
+    y9 = ops.conv3x3(h16(rows(x)), ops.pack_conv3x3(h16(wt)), f32(b), n, h, w, ups=1)
+    assert rel_l2(y, y9) < 2e-3
+
+
+def test_upsample_conv3x3_parity_rejects_other_geometry(ops):
+    from lavie_amd import _lib
+    lib = _lib.load()
+    assert lib.lavie_upsample_conv3x3_supported(2, 6, 12, 320) == 0          # 12-pixel rows do not tile 320
+    assert lib.lavie_upsample_conv3x3_supported(2, 10, 16, 256) == 0         # 256 channels: no 160-wide column tile
+    with pytest.raises(RuntimeError):
+        ops.upsample_conv3x3(torch.zeros(2 * 6 * 12, 320, dtype=torch.float16, device="cuda"),
+                             torch.zeros(4, 320, 1280, dtype=torch.float16, device="cuda"), torch.zeros(320, device="cuda"), 2, 6, 12)
+
+
 def test_conv3x3_residual(ops):
     g = gen(12)
     n, h, w, c = 2, 8, 8, 64
