@@ -27,6 +27,12 @@ Extra objects on that line:
   kernel_breakdown  every kernel class, from one extra instrumented UNet forward after the timed region
   cpu_baseline      the fp32 CPU oracle (kind "port") on this host's cores: 1 warm-up + 2 timed full CFG denoise steps
                     (BASELINE.md §4), extrapolated x50
+  reference_order   the same job with none of the algebraic savings of the loop structure (both CFG halves computed in every layer,
+                    Upsample3D as the 9-tap conv over the upsampled image): the reference's order of work, timed after the headline
+  interp_forward    BASELINE.json configs[3] regression guard (round 4): the interpolation UNet at 61 frames, latent 40x64, guidance
+                    batch 2 — ms per DDIM step (UNet forward + fused guidance / update), its temporal kernel's HBM fraction
+  vsr_forward       BASELINE.json configs[4] regression guard: one 8-frame chunk of 320x512 latents through UNet3DVSRModel, ms per forward
+                    (both legs: single-process runs only, after the headline region, never `value`; --headline-only / --no-extra-legs skip them)
 """
 import argparse
 import ctypes
@@ -248,6 +254,90 @@ def launcher_selftest(rank, world, args):
         dist.destroy_process_group()
     return 0
 
+def _class_rows(lib, fn):
+    """one event-instrumented call of fn(): per-class rows"""
+    profile_begin(lib, 0x7FF, 8192)
+    fn()
+    return profile_end(lib)
+
+
+def interp_leg(lib, device, steps=5):
+    """BASELINE.json configs[3]: interpolation UNet (sparse-causal attn1, FF -> temporal order, 8 input channels) at F = 61,
+    latent 40x64, guidance batch 2, respaced DDIM (interpolation/configs/sample.yaml:14-37): `steps` timed DDIM steps after two
+    warm-up steps, then one instrumented forward for the class table and the temporal kernel's HBM fraction."""
+    from lavie_amd import spec, weights
+    from lavie_amd.config import INTERPOLATION_CONFIG
+    from lavie_amd.interpolation import UNet3DConditionModel as InterpUNet, create_diffusion
+    F = 61
+    sd = weights.synth_state_dict(spec.param_shapes(INTERPOLATION_CONFIG), 0)
+    net = InterpUNet(init_weights=False, sample_size=64, in_channels=8, cross_attention_dim=CTX_DIM, use_first_frame=True)
+    net.load_state_dict({k: v.half() for k, v in sd.items()})
+    del sd
+    net = net.to(device, torch.float16)
+    g = torch.Generator().manual_seed(0)
+    z = torch.cat([torch.randn(1, 4, F, LAT_H, LAT_W, generator=g)] * 2).to(device)
+    xs = torch.cat([torch.randn(1, 4, F, LAT_H, LAT_W, generator=g)] * 2).to(device)
+    ctx = torch.randn(2, CTX_LEN, CTX_DIM, generator=g).to(device)
+    d = create_diffusion("50")
+    mk = dict(encoder_hidden_states=ctx, class_labels=None)
+    d._ddim_loop_hip(net, z.shape, z, mk, 0.0, xs, True, max_steps=2)          # warm-up: packs weights, sizes the workspace
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = d._ddim_loop_hip(net, z.shape, z, mk, 0.0, xs, True, max_steps=steps)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    x8 = torch.cat([z, xs], dim=1).half()
+    rows = _class_rows(lib, lambda: net(x8, 500, encoder_hidden_states=ctx.half()))
+    temp = rows[3]
+    res = {"workload": "BASELINE.json configs[3]: interpolation UNet, 61 frames x 320x512 (latent 8x61x40x64 in, 4 out), guidance batch 2, "
+                       "one respaced-DDIM step = UNet forward + fused guidance/update, fp16, random-init 909M-param UNet",
+           "interp_forward_ms": ms, "timed_steps": steps, "outputs_finite": bool(torch.isfinite(out).all()),
+           "round2_value_ms": 90.3, "round2_source": "profiles/r02_interp_f61_bench_10steps.json",
+           "classes": [dict(name=r["name"], launches=r["launches"], ms=round(r["ms"], 3)) for r in rows if r["launches"]]}
+    if temp["launches"] and temp["ms"] > 0:
+        bw = temp["bytes"] / (temp["ms"] * 1e-3) / 1e9
+        res["temporal_kernel"] = {"kernel": "temporal_stream_kernel<NT = 4> (F = 61 padded to 64, plain softmax, no rotary / bias)",
+                                  "bound": "hbm", "achieved": bw, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bw / PEAK_HBM_GBS,
+                                  "launches": temp["launches"], "avg_launch_us": 1e3 * temp["ms"] / temp["launches"]}
+    del net
+    torch.cuda.empty_cache()
+    return res
+
+
+def vsr_leg(lib, device, iters=2):
+    """BASELINE.json configs[4], the stage that is 82 % of the cascade: one 8-frame chunk (vsr/sample.py:99-129) of 320x512 latents
+    through UNet3DVSRModel (vsr/configs/unet_3d_config.json, 691 M parameters), guidance batch 2: ms per forward."""
+    from lavie_amd import spec, weights
+    from lavie_amd.config import VSR_CONFIG
+    from lavie_amd.vsr import UNet3DVSRModel
+    F, H, W = 8, 320, 512
+    sd = weights.synth_state_dict(spec.param_shapes(VSR_CONFIG), 0)
+    net = UNet3DVSRModel(init_weights=False, sample_size=128, down_temporal_idx=(0, 1, 2, 3), mid_temporal=True, up_temporal_idx=(0, 1, 2, 3))
+    net.load_state_dict({k: v.half() for k, v in sd.items()})
+    del sd
+    net = net.to(device, torch.float16)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, F, H, W, generator=g).half().to(device)
+    low = torch.randn(2, 3, F, H, W, generator=g).half().to(device)
+    ctx = torch.randn(2, CTX_LEN, 1024, generator=g).half().to(device)
+    labels = torch.tensor([20, 20])
+    out = net(x, 500, low, encoder_hidden_states=ctx, class_labels=labels).sample      # warm-up (packs weights, sizes the workspace)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        out = net(x, 500 - i, low, encoder_hidden_states=ctx, class_labels=labels).sample
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / iters
+    rows = _class_rows(lib, lambda: net(x, 400, low, encoder_hidden_states=ctx, class_labels=labels))
+    res = {"workload": "BASELINE.json configs[4] (VSR stage, 82 % of the cascade): UNet3DVSRModel, one 8-frame chunk of 320x512 latents "
+                       "(4 noisy + 3 low-res channels), guidance batch 2, fp16, random-init 691M-param UNet",
+           "vsr_forward_ms": ms, "timed_forwards": iters, "outputs_finite": bool(torch.isfinite(out).all()),
+           "round2_value_ms": 359.0, "round2_source": "profiles/r02_vsr_unet_bench_final.json",
+           "classes": [dict(name=r["name"], launches=r["launches"], ms=round(r["ms"], 3)) for r in rows if r["launches"]]}
+    del net
+    torch.cuda.empty_cache()
+    return res
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -271,6 +361,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the legs timed after the headline region (both CFG halves computed; k prompts per forward): what "
                          "tools/collect_profiles.sh traces, so that per-kernel averages are those of the headline configuration")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the interpolation (configs[3]) and VSR (configs[4]) regression-guard legs that rank 0 runs after the headline")
     ap.add_argument("--prompts-per-forward", type=int, default=4,
                     help="after the headline (single-prompt) measurement, also time k prompts batched into ONE UNet forward "
                          "(batch 2k; SURVEY §8e 'batched B = 2k if memory-profitable'; BASELINE.json configs[2] readiness) and "
@@ -417,6 +509,32 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el2 = float(tt.item())
         both_halves = {"videos_per_rank": nv, "value": nv * world / el2, "ms_per_step": 1000.0 * el2 / nv}
+    # ---- the reference's order of work throughout: both CFG halves in every layer AND Upsample3D as the 9-tap conv over the upsampled
+    # image (the text K / V projections stay cached per prompt: no switch exists for that one, 0.09 of 16.2 TFLOP per forward)
+    reference_order = None
+    if not args.headline_only and (pipe.cfg_shared_prefix or not args.no_upsample_parity):
+        nv = min(args.steps, 2)
+        was_shared = pipe.cfg_shared_prefix
+        pipe.cfg_shared_prefix = False
+        _lib.check(lib.lavie_debug_fused_mask(~8 & ~16), "lavie_debug_fused_mask")
+        net.prepare(2, FRAMES, LAT_H, LAT_W, CTX_LEN)
+        one_video(0)
+        barrier()
+        t3 = time.perf_counter()
+        for i in range(nv):
+            one_video(args.warmup + i)
+        barrier()
+        el3 = time.perf_counter() - t3
+        pipe.cfg_shared_prefix = was_shared
+        _lib.check(lib.lavie_debug_fused_mask(~8 & ~16 if args.no_upsample_parity else ~8), "lavie_debug_fused_mask")
+        net.prepare(2, FRAMES, LAT_H, LAT_W, CTX_LEN)
+        if world > 1:
+            tt = torch.tensor([el3], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el3 = float(tt.item())
+        reference_order = {"videos_per_rank": nv, "value": nv * world / el3, "ms_per_step": 1000.0 * el3 / nv,
+                           "what": "both CFG halves computed in every layer and Upsample3D as a 9-tap conv over the upsampled image "
+                                   "(--no-cfg-shared-prefix --no-upsample-parity); text K / V still once per prompt"}
     total_videos = args.steps * world
     shared_tflop = CFG_SHARED_TFLOP if pipe.cfg_shared_prefix else 0.0
     parity_tflop = 0.0 if args.no_upsample_parity else UPSAMPLE_PARITY_TFLOP
@@ -458,6 +576,8 @@ def main():
     if batched is not None:
         batched["vs_single_prompt"] = batched["value"] / result["value"]
         result["batched"] = batched
+    if reference_order is not None:
+        result["reference_order"] = reference_order
 
     def instrumented_forwards(mask, n):
         """n UNet forwards as the guided loop runs them (cached context, shared CFG prefix), event-instrumented; class rows."""
@@ -548,6 +668,14 @@ def main():
             "classes": [dict(name=r["name"], launches=r["launches"], ms=round(r["ms"], 4),
                              tflops=(r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 and r["flops"] > 0 else None),
                              gbs=(r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else None)) for r in rows]}
+
+    # ---- regression guards for the widened configurations (never `value`): BASELINE.json configs[3] and configs[4]
+    if rank == 0 and world == 1 and not args.headline_only and not args.no_extra_legs:
+        for key, leg in (("interp_forward", interp_leg), ("vsr_forward", vsr_leg)):
+            try:
+                result[key] = leg(lib, device)
+            except Exception as e:     # a failing guard leg must not cost the headline line
+                result[key] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         result["cpu_baseline"] = cpu_baseline({k: v.float() for k, v in sd32.items()}, args.cpu_threads or host_cores(),

@@ -204,16 +204,21 @@ int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long lo
  * algorithmic flops, algorithmic bytes — the per-launch figures are defined in DESIGN.md).
  * ---------------------------------------------------------------------------------------------- */
 #define LAVIE_PROFILE_CLASSES 11
-/* Test/tuning knob for the implicit-GEMM kernel choice.  Low nibble: 0 automatic, 1 128-row kernel with the widest tile,
- * 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
- * kernel, 5 halo-patch conv kernel wherever the conv is eligible, 6 automatic without the halo-patch kernel.
- * High nibble: diagnostic ablation build of the forced kernel (results wrong). */
-/* Which row-resident fused sub-block kernels lavie_unet_forward uses: bit 0 = feed-forward (lavie_geglu_mlp_f16), bit 1 = temporal
- * attention sub-block; default all.  0 = the one-GEMM-per-launch path (A/B timing, parity cross-checks). */
+/* Which optional engine paths lavie_unet_forward takes (A/B timing, parity cross-checks).  Bits: 0 = fused feed-forward kernel
+ * (lavie_geglu_mlp_f16), 1 = fused temporal-attention sub-block (lavie_temporal_block_f16), 2 = fused text cross-attention
+ * sub-block (lavie_cross_block_f16), 3 = conv_shortcut as its own GEMM in front of a halo-patch conv2 (measured slower: OFF by
+ * default), 4 = parity form of the Upsample3D convs (lavie_upsample_conv3x3_f16), 5 = GroupNorm statistics taken from the
+ * producing kernel's epilogue instead of a statistics pass (round 4).  Default ~8 (every bit but 3).  mask & ~0x37 == 0 with
+ * bits 0-2, 4, 5 clear = the one-GEMM-per-launch path of round 2. */
 int lavie_debug_fused_mask(int mask);
 int lavie_debug_temporal_block_dump(float* buf);   /* development aid: device buffer of 100 * 64 floats, or NULL */
 int lavie_debug_rowfuse_stamps(unsigned long long* buf);   /* stamp build (variant 7): device buffer of 64 u64, or NULL */
 int lavie_debug_rowfuse_variant(int v);   /* tuning: LDS read-ahead depth of the fused kernels (0 = default) */
+/* Test/tuning knob for the implicit-GEMM kernel choice.  Low nibble: 0 automatic, 1 128-row kernel with the widest tile,
+ * 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
+ * kernel, 5 halo-patch conv kernel wherever the conv is eligible, 6 automatic without the halo-patch kernel,
+ * 7 persistent ping-pong kernel for every eligible plain GEMM, 8 automatic without it.
+ * High nibble: diagnostic ablation build of the forced kernel (results wrong), except 0xC: the halo-patch kernel's ping-pong K loop. */
 int lavie_debug_force_tile(int mode);
 /* Test/tuning knob: force the split-K factor of the implicit GEMM (0 = automatic). */
 int lavie_debug_force_splits(int s);

@@ -43,6 +43,10 @@ int fused_mask();
 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize once per kernel ADDRESS (different instantiations of one kernel template share a
+// function-pointer type, so a per-type static flag is not enough): keeps the call off the launch path and out of stream captures.
+int ensure_dynamic_lds(const void* kernel, int bytes);     // engine.cpp
+
 #ifdef __HIPCC__
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

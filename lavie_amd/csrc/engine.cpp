@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace lavie {
@@ -26,7 +27,20 @@ static int g_fused_mask = ~8;         // bit 0: fused feed-forward, bit 1: fused
 void set_fused_mask(int m) { g_fused_mask = m; }
 int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
+static bool debug_check_shared() {
+    const char* e = getenv("LAVIE_DEBUG_CHECK_SHARED");
+    return e && e[0] == '1';
+}
 unsigned long debug_epoch() { return g_debug_epoch; }
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::vector<std::pair<const void*, int>> seen;      // a handful of entries; one host thread per process drives the GPU
+    for (const auto& e : seen)
+        if (e.first == kernel && e.second >= bytes) return 0;
+    LAVIE_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    seen.emplace_back(kernel, bytes);
+    return 0;
+}
 
 #define RUN(expr)                 \
     do {                          \
@@ -1074,8 +1088,25 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
     // (conv_in, the first resnet, and GroupNorm / proj_in / self-attention of the first transformer block) the two halves of the
     // batch are the same computation.  With set_cfg_shared_input the caller vouches for sample[b] == sample[b + B/2]; those
     // layers then run on the first half and their outputs are copied (base UNet only: the first down block must have attention).
-    const bool shared = cfg_shared_input_ && c.B % 2 == 0 && cfg.attn_levels[0] && cfg.layers_per_block >= 1 && !tmod && !cfg.vsr_blocks &&
-                        cfg.num_class_embeds == 0 && !cfg.sparse_causal_attn1 && !transformers_[0].attn1_cross && !transformers_[0].tres.present;
+    const bool shared_ok = c.B % 2 == 0 && cfg.attn_levels[0] && cfg.layers_per_block >= 1 && !tmod && !cfg.vsr_blocks &&
+                           cfg.num_class_embeds == 0 && !cfg.sparse_causal_attn1 && !transformers_[0].attn1_cross && !transformers_[0].tres.present;
+    // a caller that left the switch on for a batch or model it cannot apply to gets an error, not a silently different amount of work
+    LAVIE_CHECK(!cfg_shared_input_ || shared_ok || c.dry, "forward: set_cfg_shared_input(1) needs an even batch (B=%d) and the base UNet "
+                "(attention in the first down block, no VSR / interpolation variants)", c.B);
+    const bool shared = cfg_shared_input_ && shared_ok;
+    if (shared && !c.dry && debug_check_shared()) {
+        // LAVIE_DEBUG_CHECK_SHARED=1: verify the caller's promise (sample[b] == sample[b + B/2], equal timesteps) before trusting it
+        const size_t half_bytes = (size_t)(c.B / 2) * cfg.in_channels * c.F * prep_H_ * prep_W_ * sizeof(half_t);
+        std::vector<char> h0(half_bytes), h1(half_bytes);
+        std::vector<float> ts(c.B);
+        LAVIE_HIP(hipStreamSynchronize(c.s));
+        LAVIE_HIP(hipMemcpy(h0.data(), sample, half_bytes, hipMemcpyDeviceToHost));
+        LAVIE_HIP(hipMemcpy(h1.data(), (const char*)sample + half_bytes, half_bytes, hipMemcpyDeviceToHost));
+        LAVIE_HIP(hipMemcpy(ts.data(), timesteps, c.B * sizeof(float), hipMemcpyDeviceToHost));
+        LAVIE_CHECK(memcmp(h0.data(), h1.data(), half_bytes) == 0, "forward: set_cfg_shared_input(1) but the two halves of the sample differ");
+        for (int b = 0; b < c.B / 2; ++b)
+            LAVIE_CHECK(ts[b] == ts[b + c.B / 2], "forward: set_cfg_shared_input(1) but timesteps %g / %g differ", ts[b], ts[b + c.B / 2]);
+    }
     FwdCtx ch = c;                       // the same stream / workspace / scratch, half the batch
     if (shared) ch.B = c.B / 2;
     auto dup_half = [&](half_t* p, size_t rows_full, int ch_count) -> int {
@@ -1177,12 +1208,28 @@ static int check_shape(const lavie_unet_config& cfg, int B, int F, int H, int W,
 int UNet::prepare(int B, int F, int H, int W, int ctx_len) {
     LAVIE_CHECK(finalized_, "prepare: call lavie_unet_finalize first");
     RUN(check_shape(cfg_, B, F, H, W, ctx_len));
-    DeviceArena plan;
-    plan.init_virtual();
-    FwdCtx c{nullptr, &plan, true, B, F, ctx_len, nullptr};
-    prep_H_ = H; prep_W_ = W;
-    RUN(run(c, nullptr, nullptr, nullptr, nullptr));
-    const size_t need = plan.peak() + (1 << 20);
+    // The forward may run under other switches than the ones current now (the guided loop turns the shared CFG prefix on AFTER
+    // prepare(); lavie_debug_fused_mask and the text cache change which GEMMs run, and a half-batch launch may plan another
+    // split-K slab): the plan is the maximum over every combination of them, so none of those switches can outgrow the workspace.
+    size_t peak = 0;
+    const bool shared_was = cfg_shared_input_;
+    const int mask_was = fused_mask();
+    int rc = 0;
+    for (int variant = 0; variant < 4 && rc == 0; ++variant) {
+        if ((variant & 1) && B % 2 != 0) continue;
+        cfg_shared_input_ = (variant & 1) != 0;
+        set_fused_mask((variant & 2) ? (mask_was & ~7) : mask_was);
+        DeviceArena plan;
+        plan.init_virtual();
+        FwdCtx c{nullptr, &plan, true, B, F, ctx_len, nullptr};
+        prep_H_ = H; prep_W_ = W;
+        rc = run(c, nullptr, nullptr, nullptr, nullptr);
+        if (plan.peak() > peak) peak = plan.peak();
+    }
+    cfg_shared_input_ = shared_was;
+    set_fused_mask(mask_was);
+    RUN(rc);
+    const size_t need = peak + (1 << 20);
     if (need > ws_.total_bytes()) {
         drop_graph();                               // the captured addresses die with the old workspace
         ++graph_gen_;

@@ -724,7 +724,7 @@ int launch_temporal_block(const half_t* x, half_t* y, int B, int F, int D, int C
     constexpr int lds = rf::RING_BYTES + tb::TAB_BYTES;
     const int grid = p.units < 256 ? p.units : 256;
     auto go = [&](auto kern) -> int {
-        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (int rc = ensure_dynamic_lds((const void*)kern, lds)) return rc;     // once per kernel address, not per launch
         if (prof.active()) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(rf::THREADS), lds, stream, prof.start(), prof.stop(), 0, p);
         else hipLaunchKernelGGL(kern, dim3(grid), dim3(rf::THREADS), lds, stream, p);
         LAVIE_HIP(hipGetLastError());

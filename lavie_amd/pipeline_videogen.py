@@ -9,6 +9,8 @@ PyTorch-ROCm `tokenizer`/`text_encoder`/`vae` objects to use them, or work with 
 `output_type="latent"` (what the benchmark measures: video-latents/s)."""
 from dataclasses import dataclass
 import inspect
+import os
+import sys
 from typing import Callable, List, Optional, Union
 
 import torch
@@ -43,6 +45,80 @@ class VideoGenPipeline:
             if m is not None:
                 m.to(device)
         return self
+
+    # ------------------------------------------------------------------ memory knobs of the reference pipeline object
+    # base/pipelines/sample.py:72 calls enable_xformers_memory_efficient_attention() unconditionally; the diffusers base class also
+    # offers attention slicing and the pipeline VAE slicing / tiling (pipeline_videogen.py:174-204).  They trade speed for memory in
+    # the stock attention (`_sliced_attention`, xformers) and the stock VAE; here attention is always the fused flash-style HIP
+    # kernel (scores are never materialised) and 288 GB of HBM make the VAE knobs moot, so they are accepted and change nothing.
+    def enable_xformers_memory_efficient_attention(self, attention_op=None):
+        """No-op: attn1 / attn2 always run the fused online-softmax kernel (attention.hip); nothing to switch on."""
+        return None
+
+    def disable_xformers_memory_efficient_attention(self):
+        return None
+
+    def set_attention_slice(self, slice_size="auto"):
+        """No-op (unet.py:297-360 slices the materialised score matrix; this engine has none)."""
+        return None
+
+    def enable_attention_slicing(self, slice_size="auto"):
+        return self.set_attention_slice(slice_size)
+
+    def disable_attention_slicing(self):
+        return self.set_attention_slice(None)
+
+    def enable_vae_slicing(self):
+        """Forwarded to the attached VAE when it has the switch (a stock diffusers AutoencoderKL), else a no-op."""
+        if self.vae is not None and hasattr(self.vae, "enable_slicing"):
+            self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        if self.vae is not None and hasattr(self.vae, "disable_slicing"):
+            self.vae.disable_slicing()
+
+    def enable_vae_tiling(self):
+        if self.vae is not None and hasattr(self.vae, "enable_tiling"):
+            self.vae.enable_tiling()
+
+    def disable_vae_tiling(self):
+        if self.vae is not None and hasattr(self.vae, "disable_tiling"):
+            self.vae.disable_tiling()
+
+    # ------------------------------------------------------------------ the reference's YAML (base/configs/sample.yaml:16-40)
+    @staticmethod
+    def from_sample_yaml(path_or_dict, unet, vae=None, text_encoder=None, tokenizer=None):
+        """Builds (pipeline, call_kwargs, cfg) from the keys base/pipelines/sample.py reads off its OmegaConf object:
+        `sample_method` + `beta_start` / `beta_end` / `beta_schedule` choose and configure the scheduler (sample.py:44-63),
+        `video_length`, `image_size`, `num_sampling_steps`, `guidance_scale` become the `__call__` keywords of sample.py:83-89,
+        `seed` is returned in cfg for torch.manual_seed (sample.py:22-23).  `use_fp16` and
+        `enable_xformers_memory_efficient_attention` are read by nobody in sample.py and are ignored here as well.
+        PyYAML's safe loader replaces omegaconf (absent from the image); interpolation / `${...}` references are not resolved."""
+        if isinstance(path_or_dict, dict):
+            cfg = dict(path_or_dict)
+        else:
+            import yaml
+            with open(path_or_dict) as f:
+                cfg = yaml.safe_load(f) or {}
+        method = cfg.get("sample_method", "ddpm")
+        betas = dict(beta_start=float(cfg.get("beta_start", 1e-4)), beta_end=float(cfg.get("beta_end", 0.02)),
+                     beta_schedule=cfg.get("beta_schedule", "linear"))
+        if method == "ddpm":
+            scheduler = DDPMScheduler(**betas)
+        elif method == "ddim":
+            from .scheduling_ddim import DDIMScheduler
+            scheduler = DDIMScheduler(**betas)
+        elif method == "eulerdiscrete":
+            from .scheduling_euler_discrete import EulerDiscreteScheduler
+            scheduler = EulerDiscreteScheduler(**betas)
+        else:
+            raise NotImplementedError(f"sample_method {method!r} (sample.py:44-63 knows ddim / eulerdiscrete / ddpm)")
+        size = cfg.get("image_size", [320, 512])
+        call_kwargs = dict(video_length=int(cfg.get("video_length", 16)), height=int(size[0]), width=int(size[1]),
+                           num_inference_steps=int(cfg.get("num_sampling_steps", 50)),
+                           guidance_scale=float(cfg.get("guidance_scale", 7.5)))
+        pipe = VideoGenPipeline(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet, scheduler=scheduler)
+        return pipe, call_kwargs, cfg
 
     @property
     def device(self):
@@ -174,6 +250,8 @@ class VideoGenPipeline:
         try:                                     # an exception in a callback or kernel must not leave the engine holding ctx
             if shared:
                 self.unet.set_cfg_shared_input(True)
+                if os.environ.get("LAVIE_DEBUG_CHECK_SHARED") == "1" and not torch.equal(model_in[:p], model_in[p:]):
+                    raise RuntimeError("cfg_shared_prefix: the two halves of the model input differ")
             for i, t in enumerate(timesteps):
                 eps = self.unet(model_in, t_dev[i], encoder_hidden_states=ctx).sample      # line 670
                 coeffs = sch.coefficients(t, eta) if takes_eta else sch.coefficients(t)
@@ -213,10 +291,20 @@ class VideoGenPipeline:
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t, x)
         finally:
-            if shared:
-                self.unet.set_cfg_shared_input(False)
-            if hasattr(self.unet, "cache_context"):
-                self.unet.cache_context(None)
+            # clean-up must not mask an exception raised inside the loop: each call is attempted, a failure of its own is re-raised
+            # only when the loop itself finished
+            pending = sys.exc_info()[1]
+            cleanup_error = None
+            for undo in ((lambda: self.unet.set_cfg_shared_input(False)) if shared else None,
+                         (lambda: self.unet.cache_context(None)) if hasattr(self.unet, "cache_context") else None):
+                if undo is None:
+                    continue
+                try:
+                    undo()
+                except Exception as e:      # noqa: BLE001
+                    cleanup_error = cleanup_error or e
+            if cleanup_error is not None and pending is None:
+                raise cleanup_error
         return x
 
     @torch.no_grad()

@@ -85,7 +85,20 @@ class DDIMScheduler:
         unknown = set(overrides) - set(cls._CONFIG_KEYS)
         if unknown:
             raise TypeError(f"from_config: unknown scheduler fields {sorted(unknown)}")
+        # Keys outside _CONFIG_KEYS are dropped only while they are inert.  One that would change the schedule or the step if a
+        # diffusers scheduler read it (and this class does not model it) is an error, not a silently different sampler.
+        merged = dict(config)
+        merged.update(overrides)
+        for key, inert in cls._UNMODELLED_DEFAULTS.items():
+            if key in merged and merged[key] not in inert:
+                raise NotImplementedError(f"from_config: {key}={merged[key]!r} changes the schedule / step and is not modelled here "
+                                          f"(accepted: {list(inert)})")
         return cls(**cfg)
+
+    # key -> values under which it does nothing (diffusers' own defaults); anything else raises in from_config
+    _UNMODELLED_DEFAULTS = {"trained_betas": (None,), "rescale_betas_zero_snr": (False,), "dynamic_thresholding_ratio": (0.995,),
+                            "clip_sample_range": (1.0,), "sample_max_value": (1.0,)}
+
     def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:    # :184-196
         return sample
 

@@ -305,6 +305,51 @@ def test_full_size_forward_vs_oracle(full):
         assert rel_l2(got_s[0], ref[0]) < TOL_UNET and rel_l2(got_s[1], ref[1]) < TOL_UNET
 
 
+def test_full_size_graph_replay_matches_eager(full):
+    """hipGraph replay at the production shape, the way the guided loop would drive it: cached context + shared CFG prefix, so the
+    capture contains the three row-resident level-0 kernels, the parity-form upsample convs and the half-batch copies of the shared
+    prefix (none of which the reduced-width graph tests reach).  Eager, capture, replay: bit-equal to the eager forward."""
+    import bench
+    net, _ = full
+    pe, ne, lat = bench.synth_inputs(0, "cpu")
+    ctx = torch.cat([ne, pe]).half().cuda()
+    xs = [torch.cat([lat, lat]).half().cuda() * s for s in (1.0, 0.5, 0.25, 0.75)]
+    ts = [900, 600, 300, 100]
+    try:
+        cc = net.cache_context(ctx)
+        net.set_cfg_shared_input(True)
+        ref = [net(x, t, encoder_hidden_states=cc).sample.clone() for x, t in zip(xs, ts)]
+        net.enable_graph(True)
+        buf = torch.empty_like(xs[0])
+        for i, (x, t) in enumerate(zip(xs, ts)):          # call 0 eager, 1 captures, 2.. replay
+            buf.copy_(x)
+            assert torch.equal(net(buf, t, encoder_hidden_states=cc).sample, ref[i]), f"step {i}"
+    finally:
+        net.enable_graph(False)
+        net.set_cfg_shared_input(False)
+        net.cache_context(None)
+
+
+def test_debug_check_shared_catches_unequal_halves(small, monkeypatch):
+    """LAVIE_DEBUG_CHECK_SHARED=1: with set_cfg_shared_input(True) the engine verifies sample[b] == sample[b + B/2] before it
+    computes the shared layers once; equal halves pass, unequal halves are an error instead of a silently wrong conditional half."""
+    net, _ = small
+    g = torch.Generator().manual_seed(5)
+    half = torch.randn(1, 4, 4, 8, 8, generator=g).half().cuda()
+    other = torch.randn(1, 4, 4, 8, 8, generator=g).half().cuda()
+    ctx = torch.randn(2, 77, 128, generator=g).half().cuda()
+    monkeypatch.setenv("LAVIE_DEBUG_CHECK_SHARED", "1")
+    try:
+        net.set_cfg_shared_input(True)
+        net(torch.cat([half, half]), 500, encoder_hidden_states=ctx)
+        with pytest.raises(RuntimeError, match="halves of the sample differ"):
+            net(torch.cat([half, other]), 500, encoder_hidden_states=ctx)
+        with pytest.raises(RuntimeError, match="even batch"):            # the switch on a batch it cannot apply to
+            net(half, 500, encoder_hidden_states=ctx[:1])
+    finally:
+        net.set_cfg_shared_input(False)
+
+
 def test_three_ddpm_steps_golden(full):
     """VideoGenPipeline loop (CFG + fused DDPM step) for 3 steps against the reference-UNet trajectory."""
     from lavie_amd.pipeline_videogen import VideoGenPipeline

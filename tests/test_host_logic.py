@@ -297,3 +297,103 @@ def test_ddim_from_config_takes_the_callers_scheduler_config(tmp_path):
     assert torch.equal(ref.alphas_cumprod, got.alphas_cumprod)
     with pytest.raises(TypeError):
         DDIMScheduler.from_config(cfg, no_such_field=1)
+
+
+def test_ddim_from_config_refuses_keys_that_would_change_the_schedule():
+    """Keys this class does not model are dropped only while they are inert (their diffusers defaults); a non-null
+    trained_betas or rescale_betas_zero_snr=true would make a diffusers scheduler run other betas: an error here."""
+    from lavie_amd.scheduling_ddim import DDIMScheduler
+    base = {"beta_schedule": "linear", "trained_betas": None, "rescale_betas_zero_snr": False, "skip_prk_steps": True,
+            "_class_name": "PNDMScheduler", "clip_sample_range": 1.0}
+    DDIMScheduler.from_config(base)
+    for key, val in (("trained_betas", [0.1, 0.2]), ("rescale_betas_zero_snr", True), ("clip_sample_range", 2.0)):
+        with pytest.raises(NotImplementedError):
+            DDIMScheduler.from_config(dict(base, **{key: val}))
+
+
+class _StubUNet:
+    """what VideoGenPipeline touches outside the denoise loop"""
+    class config:
+        in_channels, sample_size = 4, 64
+    device = torch.device("cpu")
+
+    def to(self, device):
+        self.moved_to = device
+        return self
+
+
+def test_pipeline_object_walks_the_reference_callers_sequence(monkeypatch):
+    """base/pipelines/sample.py:65-89 as a caller sees the pipeline object: the seven constructor keywords, `.to(device)`,
+    `enable_xformers_memory_efficient_attention()` (line 72, unconditional), then `pipeline(prompt, image_tensor, video_length=,
+    height=, width=, num_inference_steps=, guidance_scale=).video` with the second POSITIONAL argument the fork added (accepted and,
+    as in the fork — its image branch sits inside a string literal, pipeline_videogen.py:350-358 — not used).  The denoiser itself is
+    stubbed: this is the CPU half of the contract; tests/test_gpu_engine.py runs the loop."""
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    seen = {}
+
+    def fake_denoise(self, latents, ctx, steps, scale, generator=None, callback=None, callback_steps=1, eta=0.0):
+        seen.update(latents=tuple(latents.shape), ctx=tuple(ctx.shape), steps=steps, scale=scale)
+        return latents
+
+    monkeypatch.setattr(VideoGenPipeline, "denoise", fake_denoise)
+    unet = _StubUNet()
+    pipe = VideoGenPipeline(vae=None, text_encoder=None, tokenizer=None, scheduler=DDPMScheduler(beta_start=1e-4, beta_end=0.02,
+                            beta_schedule="linear"), unet=unet, clip_model=object(), clip_processor=object()).to("cpu")
+    assert unet.moved_to == "cpu"
+    assert pipe.enable_xformers_memory_efficient_attention() is None          # sample.py:72
+    for knob in (pipe.disable_xformers_memory_efficient_attention, pipe.enable_vae_slicing, pipe.disable_vae_slicing,
+                 pipe.enable_vae_tiling, pipe.disable_vae_tiling, pipe.enable_attention_slicing, pipe.disable_attention_slicing):
+        assert knob() is None
+    assert pipe.set_attention_slice("auto") is None
+    pe, ne = torch.zeros(1, 77, 768), torch.zeros(1, 77, 768)
+    image_tensor = torch.zeros(1, 3, 224, 224)
+    out = pipe(None, image_tensor, video_length=16, height=320, width=512, num_inference_steps=50, guidance_scale=7.5,
+               prompt_embeds=pe, negative_prompt_embeds=ne, output_type="latent")
+    assert tuple(out.video.shape) == (1, 4, 16, 40, 64)
+    assert seen == {"latents": (1, 4, 16, 40, 64), "ctx": (2, 77, 768), "steps": 50, "scale": 7.5}
+    with pytest.raises(ValueError):                                            # a prompt string without a tokenizer / text encoder
+        pipe("A horse playing with a ball", image_tensor, video_length=16, height=320, width=512)
+
+
+def test_from_sample_yaml_maps_the_reference_config_keys(tmp_path):
+    """base/configs/sample.yaml:16-40: the keys sample.py reads become the scheduler (sample_method + beta_*) and the call
+    keywords (video_length, image_size, num_sampling_steps, guidance_scale); the reference's own file is used when present."""
+    from lavie_amd.pipeline_videogen import VideoGenPipeline
+    from lavie_amd.scheduling_ddim import DDIMScheduler
+    from lavie_amd.scheduling_euler_discrete import EulerDiscreteScheduler
+    text = ("text_prompt: ['A horse playing with a ball']\nvideo_length: 16\nimage_size: [320, 512]\nbeta_start: 0.0001\n"
+            "beta_end: 0.02\nbeta_schedule: \"linear\"\nuse_fp16: true\nenable_xformers_memory_efficient_attention: false\n"
+            "seed: null\nguidance_scale: 7.5\nsample_method: 'ddpm'\nnum_sampling_steps: 50\n")
+    path = tmp_path / "sample.yaml"
+    path.write_text(text)
+    sources = [str(path)]
+    ref = "/root/reference/base/configs/sample.yaml"
+    if os.path.isfile(ref):
+        sources.append(ref)
+    for src in sources:
+        pipe, kw, cfg = VideoGenPipeline.from_sample_yaml(src, unet=_StubUNet())
+        assert isinstance(pipe.scheduler, DDPMScheduler)
+        assert pipe.scheduler.config.beta_start == 1e-4 and pipe.scheduler.config.beta_end == 0.02
+        assert kw == dict(video_length=16, height=320, width=512, num_inference_steps=50, guidance_scale=7.5)
+        assert cfg["seed"] is None and cfg["text_prompt"] == ["A horse playing with a ball"]
+    pipe, _, _ = VideoGenPipeline.from_sample_yaml({"sample_method": "ddim", "beta_schedule": "scaled_linear"}, unet=_StubUNet())
+    assert isinstance(pipe.scheduler, DDIMScheduler) and pipe.scheduler.config.beta_schedule == "scaled_linear"
+    pipe, _, _ = VideoGenPipeline.from_sample_yaml({"sample_method": "eulerdiscrete"}, unet=_StubUNet())
+    assert isinstance(pipe.scheduler, EulerDiscreteScheduler)
+    with pytest.raises(NotImplementedError):
+        VideoGenPipeline.from_sample_yaml({"sample_method": "pndm"}, unet=_StubUNet())
+
+
+def test_host_sanitizer_build_is_clean():
+    """`make asan` compiles every native source HOST-ONLY with AddressSanitizer + UBSan against the stub HIP
+    runtime (lavie_amd/csrc/hostcheck/) and walks the C ABI — parameter inventory, weight packing, workspace dry run, planners,
+    launch geometry, argument checks — for the base, interpolation and VSR variants.  CPU only."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "lavie_amd", "csrc"), "-j", "8", "asan"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "hostcheck: ok" in r.stdout
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr

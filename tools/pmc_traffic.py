@@ -7,7 +7,7 @@
 * MFMA busy fraction from SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE when that pass is present:
   busy / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs), i.e. the share of SIMD cycles AT THE CLOCK THE CHIP HELD in which the
   matrix pipe was executing (GRBM_GUI_ACTIVE is summed over the 8 XCDs).
-Keys: "roofline" = igemm_patch_kernel (bench.py's dominant kernel), "conv_class" = every gathered implicit GEMM,
+Keys: "roofline" = igemm_patch_kernel<..., MODE != 3> (bench.py's dominant kernel: the 3x3 instances), "upsample_parity" = its MODE 3 launches, "conv_class" = every gathered implicit GEMM,
 "linear" = plain implicit GEMMs, "attention", "roofline_temporal", and (round 3) "roofline_fused_temporal" / "roofline_fused_feed_forward" / "roofline_fused_cross_attention"
 = the row-resident fused sub-block kernels of rowfuse.hip.
 Usage: python tools/pmc_traffic.py <dir-with-the-passes> > profiles/pmc_traffic.json"""
@@ -24,7 +24,10 @@ root = sys.argv[1]
 def classes(name):
     out = []
     if "igemm_patch_kernel" in name:
-        out += ["roofline", "conv_class"]
+        # bench.py's `roofline` object = the 3x3 instances only (template MODE 0 / 1 / 2: last argument); the parity-form upsample
+        # launches (MODE 3) have their own key.  Demangled "igemm_patch_kernel<0, 6, 5, 3>" or mangled "...ILi0ELi6ELi5ELi3EE..."
+        parity = name.replace(" ", "").split(">")[0].endswith(",3") or "Li5ELi3EE" in name or "Li4ELi3EE" in name
+        out += ["upsample_parity" if parity else "roofline", "conv_class"]
     elif "igemm_pp_kernel<true" in name or "igemm_pp_kernelILb1" in name:
         out.append("conv_class")
     elif "igemm_ppx_kernel" in name or "igemm_pp_kernel" in name:
