@@ -224,7 +224,9 @@ int lavie_debug_force_tile(int mode);
 int lavie_debug_force_splits(int s);
 /* Diagnostic: op-level conv3x3 + pack use the K order (tap, slab) instead of (slab, tap). */
 int lavie_debug_conv_tap_major(int on);
-/* Tuning knob: 16-row query tiles per wave in the attention kernel for head dims <= 64 (0 = automatic). */
+/* Tuning knob: 16-row query tiles per wave in the attention kernel for head dims <= 64 (0 = automatic).  A/B switches: 0x50 = the
+ * register-staged kernels instead of the LDS-DMA ones, 0x40 = row sums on the VALU, 0x60 = the LDS-DMA kernels with the round-3
+ * softmax (scale and running maximum applied by v_fma) instead of the round-4 one (both on the matrix pipe). */
 int lavie_debug_attention_qt(int qt);
 /* Tuning knob: LDS bytes one temporal-attention workgroup may stage (smaller = more workgroups per CU). */
 int lavie_debug_temporal_budget(int bytes);

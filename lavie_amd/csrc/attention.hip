@@ -393,7 +393,17 @@ struct AttDmaTile {
     static constexpr int KS32 = TAIL16 ? NCH * 8 / 32 : KS;
 };
 
-template <int NCH, int QT, int NBUF, bool LSUM, bool SC>
+// V2 (round 4): the loop is VALU-issue bound at head dim 40 (per 64-key tile and wave: 34 v_exp, 32 v_fma, 26 v_max, 16 v_cvt_pk
+// beside 28 MFMAs, and an MFMA itself holds the vector issue port for 8 of its 16 cycles), so the softmax sheds instructions:
+//  * the softmax scale and log2(e) are folded into the Q fragments once per wave (Q' = fp16(Q scale log2 e): one more fp16
+//    rounding of Q, ~2^-12 relative per element), so the scores leave the matrix pipe in log2 units;
+//  * the running maximum is SUBTRACTED BY THE MATRIX PIPE: the first MFMA of every score tile takes C = {-m, -m, -m, -m} (four
+//    registers per query tile, rewritten only when the maximum moves), so p = exp2(S') with no v_fma at all: -32 VALU per tile;
+//  * the per-tile maximum is only needed to DECIDE whether the running maximum must move (deferred rescale, threshold 2^8): the
+//    16 in-lane values are folded with v_max3 (8 slots), the decision is one compare + ballot over the wave, and the cross-lane
+//    maximum (2 permlane swaps + 2 max) moves into the rare branch that takes it: -8 VALU per tile.
+// Softmax is invariant to the shift, so results differ from V1 only by the rounding of Q' and of exp2's argument.
+template <int NCH, int QT, int NBUF, bool LSUM, bool SC, bool V2 = true>
 __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void attention_dma_kernel(const AttnParams p) {
     using T = AttDmaTile<NCH, LSUM>;
     constexpr int R = T::R, RS = T::RS, PIECES = T::PIECES, NDT = T::NDT;
@@ -430,6 +440,15 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
         const int dtl = T::KS32 * 32 + g * 4;
         qtail[qt] = (half4_t){0, 0, 0, 0};
         if (T::TAIL16 && dtl < dh) qtail[qt] = *reinterpret_cast<const half4_t*>(qrow + dtl);
+        if constexpr (V2) {       // scores in log2 units straight from the matrix pipe
+            const float qs = p.scale * 1.4426950408889634f;
+#pragma unroll
+            for (int ks = 0; ks < T::KS32; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (half_t)((float)qf[qt][ks][j] * qs);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qtail[qt][j] = (half_t)((float)qtail[qt][j] * qs);
+        }
     }
 
     const half_t* kbase = p.k + (SC ? (size_t)0 : (size_t)kvb * p.Lk * p.ldk) + head * dh;
@@ -475,6 +494,9 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
     float m_run[QT], l_run[QT];      // running max (log2 units, scaled) and per-lane partial row sums
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -INFINITY; l_run[qt] = 0.f; }
+    f32x4 negm[QT];                  // V2: the accumulator initialiser of the score tiles, {-m, -m, -m, -m} (0 before the first tile)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) negm[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const float sl2 = p.scale * 1.4426950408889634f;   // softmax scale folded with log2(e): p = exp2(s*sl2 - m)
     const int ntile = cdiv(p.Lk, ATT_KEYS);
@@ -508,7 +530,7 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = V2 ? negm[qt] : (f32x4){0.f, 0.f, 0.f, 0.f};     // V2: S' = S - m, for free
 #pragma unroll
         for (int ks = 0; ks < T::KS32; ++ks) {
 #pragma unroll
@@ -553,6 +575,61 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
         // ---- online softmax per query column, deferred rescale (as the register-staged kernel)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
+            if constexpr (V2) {
+                // s = (scores - m_run) in log2 units.  In-lane maximum of the lane's 16 keys (8 v_max3); whether ANY row of the wave
+                // outgrew the threshold is one compare + ballot; the first tile always takes the branch (m_run = -inf there)
+                float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), s[0][qt][2]);
+                mx = fmaxf(fmaxf(mx, s[0][qt][3]), s[1][qt][0]);
+                mx = fmaxf(fmaxf(mx, s[1][qt][1]), s[1][qt][2]);
+                mx = fmaxf(fmaxf(mx, s[1][qt][3]), s[2][qt][0]);
+                mx = fmaxf(fmaxf(mx, s[2][qt][1]), s[2][qt][2]);
+                mx = fmaxf(fmaxf(mx, s[2][qt][3]), s[3][qt][0]);
+                mx = fmaxf(fmaxf(mx, s[3][qt][1]), s[3][qt][2]);
+                mx = fmaxf(mx, s[3][qt][3]);
+                if (t == 0 || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {
+                    // rare: fold the four lane groups (the query's 64 keys), move the running maximum of the rows that grew,
+                    // rescale O (and l), shift this tile's scores and the accumulator initialiser
+                    const unsigned u = __float_as_uint(mx);
+                    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                    mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+                    const unsigned v = __float_as_uint(mx);
+                    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                    mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+                    // first tile: the maximum itself (it may be far below 0: fp16 P must not underflow); later: only growth
+                    // (a fully masked / -inf first tile keeps delta finite: 0)
+                    float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+                    delta = delta > -1e30f ? delta : 0.f;
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);        // first tile: O and l are still 0
+                    const float nmr = negm[qt][0] - delta;                      // -(running maximum); negm is 0 before the first tile
+                    if constexpr (!LSUM) l_run[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < T::DT; ++dt) o[dt][qt] *= alpha;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[kt][qt][r] -= delta;
+                    negm[qt] = (f32x4){nmr, nmr, nmr, nmr};
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    float e[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        e[r] = __builtin_amdgcn_exp2f(s[kt][qt][r]);
+                        if constexpr (!LSUM) psum += e[r];
+                    }
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const half2_t h0 = __builtin_convertvector((f32x2){e[0], e[1]}, half2_t);
+                    const half2_t h1 = __builtin_convertvector((f32x2){e[2], e[3]}, half2_t);
+                    pb[kt >> 1][qt][(kt & 1) * 4 + 0] = h0[0];
+                    pb[kt >> 1][qt][(kt & 1) * 4 + 1] = h0[1];
+                    pb[kt >> 1][qt][(kt & 1) * 4 + 2] = h1[0];
+                    pb[kt >> 1][qt][(kt & 1) * 4 + 3] = h1[1];
+                }
+                if constexpr (!LSUM) l_run[qt] += psum;
+                continue;
+            }
             // a chain of three-input maxima (v_max3_f32: 8 slots for the 16 scores; the pairwise tree took 13)
             float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), s[0][qt][2]);
             mx = fmaxf(fmaxf(mx, s[0][qt][3]), s[1][qt][0]);
@@ -660,16 +737,18 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
     }
 }
 
+static int g_force_qt = 0;
 template <int NCH, int QT, int NBUF, bool LSUM, bool SC>
 static int launch_att_dma(const AttnParams& p, hipStream_t stream) {
     using T = AttDmaTile<NCH, LSUM>;
     constexpr int lds = NBUF * 2 * T::TILE_BYTES + 1024;     // + slack: the last row's MFMA-width reads run past the tile
-    auto kern = attention_dma_kernel<NCH, QT, NBUF, LSUM, SC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LAVIE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    // 0x60: A/B switch, the round-2/3 softmax (scale + maximum applied by v_fma, cross-lane maximum every tile)
+    // (head dims 128 / 160 keep it: they are MFMA-bound, and the four initialiser registers per query tile would push the
+    // 32-row instantiations past 256 VGPRs = from two waves per SIMD to one)
+    constexpr bool V2_OK = NCH <= 10;
+    auto kern = (g_force_qt == 0x60 || !V2_OK) ? attention_dma_kernel<NCH, QT, NBUF, LSUM, SC, false>
+                                                : attention_dma_kernel<NCH, QT, NBUF, LSUM, SC, V2_OK>;
+    if (int rc = ensure_dynamic_lds((const void*)kern, lds)) return rc;
     dim3 grid(cdiv(p.Lq, 4 * QT * 16), p.heads, p.NBq);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     LAVIE_HIP(hipGetLastError());
@@ -692,7 +771,6 @@ static int launch_att(const AttnParams& p, hipStream_t stream) {
 }
 
 // Kernel choice by head dim: the model's head dims (40, 80, 160; 64 for completeness) get the compile-time output-tile count.
-static int g_force_qt = 0;
 void attention_force_qt(int qt) { g_force_qt = qt; }
 
 template <bool SC>

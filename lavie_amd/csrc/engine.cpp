@@ -23,7 +23,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 static unsigned long g_debug_epoch = 0;
-static int g_fused_mask = ~8;         // bit 0: fused feed-forward, bit 1: fused temporal sub-block, bit 2: fused text cross-attention, bit 3: conv_shortcut as its own GEMM in front of a halo-patch conv2, bit 4: parity form of the upsample convs (A/B switch)
+static int g_fused_mask = ~8;         // bit 0: fused feed-forward, 1: fused temporal sub-block, 2: fused text cross-attention, 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (off), 4: parity form of the upsample convs, 5: GroupNorm statistics from the producers' epilogues (A/B switches)
 void set_fused_mask(int m) { g_fused_mask = m; }
 int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
@@ -631,10 +631,33 @@ struct RowStat {           // producer side: partials [M, slots, 2] -> (mean, rs
     int slots;
 };
 
+// GroupNorm statistics from the producing kernel (igemm.h colstat_out, round 4).  Every tensor a GroupNorm may read gets a small
+// buffer next to it (same workspace lifetime); the launcher that writes the tensor fills it and describes it in a GnColStat that
+// travels WITH the tensor through the wiring below (explicitly, never keyed by address: workspace addresses are reused).
+static size_t colstat_floats(size_t M, int C) { return (M / COLSTAT_REDUCE_ROWS + 8) * (size_t)C * 2; }
+static bool colstat_on() { return (fused_mask() & 32) != 0; }
+// plan: which block height will the launch of `p` write (0 = none), and describe the result
+static void colstat_plan(IgemmParams& p, bool gather, float* buf, GnColStat* out) {
+    if (out) *out = GnColStat();
+    p.colstat_out = nullptr;
+    p.colstat_rows = 0;
+    if (!buf || !out || !colstat_on()) return;
+    const int rows = igemm_colstat_rows(p, gather, EPI_LINEAR);
+    if (rows <= 0) return;
+    p.colstat_out = buf;
+    p.colstat_rows = rows;
+    out->partials = buf;
+    out->C = p.N;
+    out->rows = rows;
+    if (p.par_ups && p.splits == 1) { out->nsets = 4; out->set_blocks = p.M / 4 / rows; }     // source-row blocks per output parity
+    else { out->nsets = 1; out->set_blocks = cdiv(p.M, rows); }                               // (split-K: the reduce kernel walks output rows)
+}
+
 static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const float* bias, int N, int K, const half_t* R,
                   half_t* C, int ldc, int M, int epilogue = EPI_LINEAR, const LnFold* fold = nullptr,
-                  const RowStat* rowstat = nullptr, int ldw = 0) {
+                  const RowStat* rowstat = nullptr, int ldw = 0, float* cs_buf = nullptr, GnColStat* cs_out = nullptr) {
     const bool unsplit = fold != nullptr || rowstat != nullptr;
+    if (cs_out) *cs_out = GnColStat();
     if (c.dry) {   // plan the split-K slab so that prepare() sizes the workspace for it
         const int s = unsplit ? 1 : igemm_plan_splits(M, N, K / IGEMM_BK, epilogue);
         if (s > 1) {
@@ -653,6 +676,7 @@ static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const fl
     p.rowstat_out = rowstat ? rowstat->partials : nullptr;
     p.rowstat_cols = rowstat ? N / rowstat->slots : 0;
     if (fold) { p.ln_stats = fold->stats; p.ln_s = fold->s; }
+    if (epilogue == EPI_LINEAR && ldc == N) colstat_plan(p, false, cs_buf, cs_out);
     const size_t mark = c.ws->mark();
     if (p.splits > 1) {
         p.slab = (float*)c.ws->alloc((size_t)p.splits * M * N * sizeof(float));
@@ -667,7 +691,8 @@ static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const fl
 // 3x3 conv (pad 1) over `nsrc` channel-concatenated sources, plus optional centre-tap shortcut sources.
 static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsrc, const half_t* const* sc, const int* scC,
                    int nsc, const half_t* W, int ldw, const float* bias, const float* bias2, int ldb2, int rows_per_batch,
-                   const half_t* R, half_t* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const half_t* zero) {
+                   const half_t* R, half_t* y, int NI, int Hi, int Wi, int Cout, int stride, int ups, const half_t* zero,
+                   float* cs_buf = nullptr, GnColStat* cs_out = nullptr) {
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.W = W; p.ldw = ldw; p.C = y; p.ldc = Cout; p.bias = bias; p.bias2 = bias2; p.ldb2 = ldb2;
@@ -696,6 +721,7 @@ static int conv3x3(FwdCtx& c, const half_t* const* src, const int* srcC, int nsr
     p.nseg = ns;
     p.nk = nk;
     p.splits = igemm_plan_splits_gather(p);        // also picks the kernel: same inputs -> same choice in the dry run
+    colstat_plan(p, true, cs_buf, cs_out);
     const size_t mark = c.ws->mark();
     if (p.splits > 1) {
         p.slab = (float*)c.ws->alloc((size_t)p.splits * p.M * p.N * sizeof(float));
@@ -779,7 +805,8 @@ int UNet::run_temporal_module(FwdCtx& c, const TemporalModuleW& m, const half_t*
 }
 
 int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, const float* tproj,
-                     int ld_tproj, half_t* y, int H, int W) {
+                     int ld_tproj, half_t* y, int H, int W, const GnColStat* cs1, const GnColStat* cs2, float* y_csbuf,
+                     GnColStat* y_cs) {
     LAVIE_CHECK(C1 + C2 == r.cin, "resnet %s: got %d+%d input channels, expected %d", r.prefix.c_str(), C1, C2, r.cin);
     const int G = cfg_.norm_groups;
     const int NI = c.B * c.F;
@@ -789,15 +816,19 @@ int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, cons
     WS(nrm, half_t, M * r.cin);
     WS(h1, half_t, M * r.cout);
     WS(n2, half_t, M * r.cout);
+    WS(h1cs, float, colstat_floats(M, r.cout));      // GroupNorm statistics of h1, written by conv1's epilogue
+    GnColStat h1_cs;
+    if (y_cs) *y_cs = GnColStat();
     const float eps = r.eps > 0.f ? r.eps : cfg_.norm_eps;
-    LAUNCH(launch_group_norm(x1, C1, x2, C2, c.B, P, G, r.n1.g, r.n1.b, eps, true, c.gn_ws, nrm, c.s));
+    // norm1: statistics from the producers of x1 / x2 where they left them (cs1 / cs2), else the statistics pass
+    LAUNCH(launch_group_norm(x1, C1, x2, C2, c.B, P, G, r.n1.g, r.n1.b, eps, true, c.gn_ws, nrm, c.s, cs1, cs2));
     {
         const half_t* src[1] = {nrm};
         const int srcC[1] = {r.cin};
         RUN(conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, r.w1, 9 * r.cin, r.b1, tproj, ld_tproj, P, nullptr, h1, NI, H, W,
-                    r.cout, 1, 0, zero_page_));
+                    r.cout, 1, 0, zero_page_, h1cs, &h1_cs));
     }
-    LAUNCH(launch_group_norm(h1, r.cout, nullptr, 0, c.B, P, G, r.n2.g, r.n2.b, eps, true, c.gn_ws, n2, c.s));
+    LAUNCH(launch_group_norm(h1, r.cout, nullptr, 0, c.B, P, G, r.n2.g, r.n2.b, eps, true, c.gn_ws, n2, c.s, &h1_cs));
     {
         const half_t* src[1] = {n2};
         const int srcC[1] = {r.cout};
@@ -816,17 +847,19 @@ int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, cons
             const half_t* wsc = r.w2 + 9 * r.cout;
             if (nsc == 1) RUN(linear(c, x1, C1, wsc, nullptr, r.cout, C1, nullptr, scy, r.cout, (int)M, EPI_LINEAR, nullptr, nullptr, r.ldw2));
             else RUN(conv3x3(c, nullptr, nullptr, 0, sc, scC, nsc, wsc, r.ldw2, nullptr, nullptr, 0, 1, nullptr, scy, NI, H, W, r.cout, 1, 0, zero_page_));
-            RUN(conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, r.w2, r.ldw2, r.b2, nullptr, 0, 1, scy, y, NI, H, W, r.cout, 1, 0, zero_page_));
+            RUN(conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, r.w2, r.ldw2, r.b2, nullptr, 0, 1, scy, y, NI, H, W, r.cout, 1, 0, zero_page_,
+                        y_csbuf, y_cs));
         } else {
         RUN(conv3x3(c, src, srcC, 1, sc, scC, nsc, r.w2, r.ldw2, r.b2, nullptr, 0, 1, r.shortcut ? nullptr : x1, y, NI, H, W,
-                    r.cout, 1, 0, zero_page_));
+                    r.cout, 1, 0, zero_page_, y_csbuf, y_cs));
         }
     }
     c.ws->release(mark);
     return 0;
 }
 
-int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W, bool shared_prefix) {
+int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W, bool shared_prefix,
+                          GnColStat* x_cs, float* x_csbuf) {
     const int C = t.C, G = cfg_.norm_groups, heads = cfg_.heads, dh = C / heads;
     const int NI = c.B * c.F, D = H * W;
     const int T = NI * D;
@@ -843,14 +876,17 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     const bool kv_cached = !c.dry && kv_ctx_ != nullptr && kv_ctx_ == ctx && kv_B_ == c.B && kv_len_ == c.ctx_len && ti < kv2_cache_.size();
 
     // VSR: ResnetBlock3DCNN (3,1,1) on the block input, before the residual is taken (vsr/models/attention.py:395-400)
-    if (t.tres.present) RUN(run_temporal_res(c, t.tres, x, x, C, D, nullptr, 0));
+    if (t.tres.present) {
+        RUN(run_temporal_res(c, t.tres, x, x, C, D, nullptr, 0));
+        if (x_cs) *x_cs = GnColStat();         // x rewritten in place by kernels that leave no statistics
+    }
     // shared_prefix (set_cfg_shared_input; base block only): both halves of the batch are identical up to the text
     // cross-attention, so GroupNorm, proj_in, the qkv projection and the self-attention run on the first half (NIp frames,
     // Tp rows) and `tx` / `att` are copied to the second
     const int NIp = shared_prefix ? NI / 2 : NI, Tp = shared_prefix ? T / 2 : T;
     LAVIE_CHECK(!shared_prefix || (!t.tres.present && !t.attn1_cross && c.B % 2 == 0), "transformer: shared prefix on an unsupported block");
     // per-frame GroupNorm (eps 1e-6) + 1x1 proj_in (attention.py:369-373)
-    LAUNCH(launch_group_norm(x, C, nullptr, 0, NIp, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s));
+    LAUNCH(launch_group_norm(x, C, nullptr, 0, NIp, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s, x_cs));
     // LayerNorm folding: the GEMM that produces the residual stream `tx` also emits per-row (sum, sum^2) partials of
     // its fp16 output, and the projection that consumes LN(tx) runs on raw `tx` with gamma folded into its weights,
     // finishing rstd * (acc - mean * s) + b' in its epilogue — no LayerNorm kernel, no normalised copy in HBM.
@@ -1007,12 +1043,15 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     }
 
     // 1x1 proj_out + residual, in place on the block input (attention.py:394-401)
-    RUN(linear(c, tx, C, t.pout.w, t.pout.b, C, C, x, x, C, T));
+    // (its epilogue leaves the GroupNorm statistics of the block's output for the next resnet / skip consumer: x_cs is rewritten)
+    RUN(linear(c, tx, C, t.pout.w, t.pout.b, C, C, x, x, C, T, EPI_LINEAR, nullptr, nullptr, 0, x_csbuf, x_cs));
     c.ws->release(mark);
     return 0;
 }
 
-int UNet::run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups) {
+int UNet::run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups, float* cs_buf,
+                   GnColStat* cs_out) {
+    if (cs_out) *cs_out = GnColStat();
     const half_t* src[1] = {x};
     const int srcC[1] = {C};
     if (ups && stride == 1 && w.wpar && (fused_mask() & 16)) {
@@ -1020,6 +1059,7 @@ int UNet::run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t*
         // output parity, on the halo-patch kernel (igemm_patch.hip MODE 3): 4 C instead of 9 C multiply-adds per output element
         IgemmParams p;
         if (igemm_setup_parity_upsample(&p, x, C, w.wpar, w.b, y, c.B * c.F, Hi, Wi, zero_page_)) {
+            colstat_plan(p, true, cs_buf, cs_out);
             const size_t mark = c.ws->mark();
             if (p.splits > 1) {
                 p.slab = (float*)c.ws->alloc((size_t)p.splits * p.M * p.N * sizeof(float));
@@ -1031,7 +1071,7 @@ int UNet::run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t*
         }
     }
     return conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, w.w, 9 * C, w.b, nullptr, 0, 1, nullptr, y, c.B * c.F, Hi, Wi, C, stride,
-                   ups, zero_page_);
+                   ups, zero_page_, cs_buf, cs_out);
 }
 
 int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out) {
@@ -1079,7 +1119,8 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
     // prep_H_/prep_W_ hold the CURRENT call's size while run() executes (set by forward()/prepare())
     auto rows = [&](int l) { return (size_t)NI * Hs[l] * Ws[l]; };
 
-    struct Skip { half_t* p; int C; };
+    struct Skip { half_t* p; int C; GnColStat cs; };     // a skip tensor travels with the statistics its producer left
+    GnColStat x_cs;                                      // ... and so does the running activation x
     std::vector<Skip> skips;
     size_t ri = 0, ti = 0, mi = 0;
     const bool tmod = cfg.vsr_temporal_modules != 0;
@@ -1120,47 +1161,55 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
     RUN(dup_half(x0, rows(0), C0));
     half_t* x = x0;
     int C = C0;
-    skips.push_back({x, C});
+    skips.push_back({x, C, x_cs});                      // conv_in leaves no statistics: its two consumers run the statistics pass
 
     for (int l = 0; l < L; ++l) {
         for (int j = 0; j < cfg.layers_per_block; ++j) {
             const ResnetW& r = resnets_[ri++];
             WS(y, half_t, rows(l) * r.cout);
+            WS(ycs, float, colstat_floats(rows(l), r.cout));
+            GnColStat y_cs;
             const bool first = shared && l == 0 && j == 0;
-            RUN(run_resnet(first ? ch : c, r, x, C, nullptr, 0, tproj + r.temb_off, tproj_.N, y, Hs[l], Ws[l]));
-            if (first) RUN(dup_half(y, rows(l), r.cout));
-            x = y; C = r.cout;
-            if (cfg.attn_levels[l]) RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l], first));
-            skips.push_back({x, C});
+            RUN(run_resnet(first ? ch : c, r, x, C, nullptr, 0, tproj + r.temb_off, tproj_.N, y, Hs[l], Ws[l], &x_cs, nullptr, ycs, &y_cs));
+            if (first) RUN(dup_half(y, rows(l), r.cout));     // (y_cs describes the first half: all its one consumer, the half-batch GroupNorm below, reads)
+            x = y; C = r.cout; x_cs = y_cs;
+            if (cfg.attn_levels[l]) RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l], first, &x_cs, ycs));
+            else if (first) x_cs = GnColStat();
+            skips.push_back({x, C, x_cs});
         }
         if (l + 1 < L) {
             WS(y, half_t, rows(l + 1) * C);
-            RUN(run_conv(c, x, C, downs_[l], y, Hs[l], Ws[l], 2, 0));
-            x = y;
-            skips.push_back({x, C});
+            WS(ycs, float, colstat_floats(rows(l + 1), C));
+            GnColStat y_cs;
+            RUN(run_conv(c, x, C, downs_[l], y, Hs[l], Ws[l], 2, 0, ycs, &y_cs));
+            x = y; x_cs = y_cs;
+            skips.push_back({x, C, x_cs});
         }
         if (tmod) {       // after the downsampler, into a NEW buffer: x itself stays alive as a skip (vsr/models/unet.py:523-533)
             const int ll = l + 1 < L ? l + 1 : l;
             WS(yt, half_t, rows(ll) * C);
             RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[ll], Ws[ll]));
-            x = yt;
+            x = yt; x_cs = GnColStat();
         }
     }
     {
         const int l = L - 1;
         const ResnetW& r0 = resnets_[ri++];
         WS(y0, half_t, rows(l) * r0.cout);
-        RUN(run_resnet(c, r0, x, C, nullptr, 0, tproj + r0.temb_off, tproj_.N, y0, Hs[l], Ws[l]));
-        x = y0; C = r0.cout;
-        RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l]));
+        WS(y0cs, float, colstat_floats(rows(l), r0.cout));
+        GnColStat y_cs;
+        RUN(run_resnet(c, r0, x, C, nullptr, 0, tproj + r0.temb_off, tproj_.N, y0, Hs[l], Ws[l], &x_cs, nullptr, y0cs, &y_cs));
+        x = y0; C = r0.cout; x_cs = y_cs;
+        RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l], false, &x_cs, y0cs));
         const ResnetW& r1 = resnets_[ri++];
         WS(y1, half_t, rows(l) * r1.cout);
-        RUN(run_resnet(c, r1, x, C, nullptr, 0, tproj + r1.temb_off, tproj_.N, y1, Hs[l], Ws[l]));
-        x = y1; C = r1.cout;
+        WS(y1cs, float, colstat_floats(rows(l), r1.cout));
+        RUN(run_resnet(c, r1, x, C, nullptr, 0, tproj + r1.temb_off, tproj_.N, y1, Hs[l], Ws[l], &x_cs, nullptr, y1cs, &y_cs));
+        x = y1; C = r1.cout; x_cs = y_cs;
         if (tmod) {
             WS(yt, half_t, rows(l) * C);
             RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[l], Ws[l]));
-            x = yt;
+            x = yt; x_cs = GnColStat();
         }
     }
     for (int i = 0; i < L; ++i) {
@@ -1170,27 +1219,31 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
             skips.pop_back();
             const ResnetW& r = resnets_[ri++];
             WS(y, half_t, rows(l) * r.cout);
-            RUN(run_resnet(c, r, x, C, sk.p, sk.C, tproj + r.temb_off, tproj_.N, y, Hs[l], Ws[l]));
-            x = y; C = r.cout;
-            if (cfg.attn_levels[l]) RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l]));
+            WS(ycs, float, colstat_floats(rows(l), r.cout));
+            GnColStat y_cs;
+            RUN(run_resnet(c, r, x, C, sk.p, sk.C, tproj + r.temb_off, tproj_.N, y, Hs[l], Ws[l], &x_cs, &sk.cs, ycs, &y_cs));
+            x = y; C = r.cout; x_cs = y_cs;
+            if (cfg.attn_levels[l]) RUN(run_transformer(c, transformers_[ti++], x, ctx, Hs[l], Ws[l], false, &x_cs, ycs));
         }
         if (i + 1 < L) {
             WS(y, half_t, rows(l - 1) * C);
-            RUN(run_conv(c, x, C, ups_[i], y, Hs[l], Ws[l], 1, 1));
-            x = y;
+            WS(ycs, float, colstat_floats(rows(l - 1), C));
+            GnColStat y_cs;
+            RUN(run_conv(c, x, C, ups_[i], y, Hs[l], Ws[l], 1, 1, ycs, &y_cs));
+            x = y; x_cs = y_cs;
         }
         if (tmod) {       // after the upsampler (vsr/models/unet.py:575-590)
             const int ll = i + 1 < L ? l - 1 : l;
             WS(yt, half_t, rows(ll) * C);
             RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[ll], Ws[ll]));
-            x = yt;
+            x = yt; x_cs = GnColStat();
         }
     }
     // conv_norm_out + SiLU + conv_out (unet.py:504-506), back to the caller's NCFHW layout
     {
         WS(nrm, half_t, rows(0) * C0);
         const int P = c.F * Hs[0] * Ws[0];
-        LAUNCH(launch_group_norm(x, C0, nullptr, 0, c.B, P, G, norm_out_.g, norm_out_.b, cfg.norm_eps, true, c.gn_ws, nrm, c.s));
+        LAUNCH(launch_group_norm(x, C0, nullptr, 0, c.B, P, G, norm_out_.g, norm_out_.b, cfg.norm_eps, true, c.gn_ws, nrm, c.s, &x_cs));
         LAUNCH(launch_conv_out(nrm, conv_out_w_, conv_out_b_, out, c.B, C0, c.F, Hs[0], Ws[0], cfg.out_channels, c.s));
     }
     return 0;
@@ -1362,7 +1415,7 @@ int UNet::resnet_forward(const char* prefix, const half_t* x1, int C1, const hal
     // standalone call: private workspace sized on the fly (test seam, not the hot path)
     DeviceArena local;
     const size_t M = (size_t)B * F * H * W;
-    RUN(local.init_fixed((M * (r->cin + 2 * r->cout)) * sizeof(half_t) + (size_t)B * r->cout * 4 + (4 << 20)));
+    RUN(local.init_fixed((M * (r->cin + 2 * r->cout)) * sizeof(half_t) + (size_t)B * r->cout * 4 + colstat_floats(M, r->cout) * sizeof(float) + (4 << 20)));
     FwdCtx c{stream, &local, false, B, F, 0, nullptr};
     c.gn_ws = (float*)local.alloc(gn_workspace_floats(B * F, cfg_.norm_groups) * sizeof(float));
     float* tproj = (float*)local.alloc((size_t)B * r->cout * sizeof(float));

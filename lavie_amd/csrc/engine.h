@@ -146,10 +146,16 @@ private:
     int ensure_tables(int F, hipStream_t s);
 
     int run(FwdCtx& c, const half_t* sample, const float* timesteps, const half_t* ctx, half_t* out);
+    // cs1 / cs2: GroupNorm statistics the producers of x1 / x2 left (nullptr / empty = none: the statistics pass runs); y_csbuf / y_cs:
+    // where the block's last conv leaves the statistics of y for ITS consumers (engine.cpp colstat_plan)
     int run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, const half_t* x2, int C2, const float* tproj,
-                   int ld_tproj, half_t* y, int H, int W);
-    int run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W, bool shared_prefix = false);
-    int run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups);
+                   int ld_tproj, half_t* y, int H, int W, const GnColStat* cs1 = nullptr, const GnColStat* cs2 = nullptr,
+                   float* y_csbuf = nullptr, GnColStat* y_cs = nullptr);
+    // x_cs: in = statistics of the block input (for its per-frame GroupNorm), out = statistics of the block output (proj_out's epilogue)
+    int run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const half_t* ctx, int H, int W, bool shared_prefix = false,
+                        GnColStat* x_cs = nullptr, float* x_csbuf = nullptr);
+    int run_conv(FwdCtx& c, const half_t* x, int C, const SamplerW& w, half_t* y, int Hi, int Wi, int stride, int ups,
+                 float* cs_buf = nullptr, GnColStat* cs_out = nullptr);
 
     struct GraphKey {
         const void *sample = nullptr, *t = nullptr, *ctx = nullptr, *out = nullptr, *kv_ctx = nullptr;

@@ -43,6 +43,13 @@ struct IgemmParams {
                                // the kernel it selects writes slots of exactly this width (0 = unchecked)
     const float* ln_stats;     // [M, 2] (mean, rstd) of the A rows (launch_rowstat_finalize), or nullptr
     const float* ln_s;         // [N]: s_n = sum_k W'[n, k]
+    // GroupNorm statistics from the producer (round 4): per (row block, channel) sum and sum of squares of the ROUNDED fp16 output,
+    // written by the epilogue that stores the tensor (or by the split-K reduce), so that the consuming GroupNorm needs no statistics
+    // pass over the tensor (resnet.py:180,191; attention.py:369; unet.py:504).  Layout (cs_index below): per block and channel quad
+    // four sums then four sums of squares.  A block = the rows of one wave tile (colstat_rows = 16 * MT of the kernel that runs, 32
+    // for the split-K reduce); the parity-form upsample conv writes four sets of source-row blocks (one per output parity).
+    float* colstat_out;        // [sets][ceil(rows / colstat_rows)][N / 4][2][4] or nullptr (EPI_LINEAR only)
+    int colstat_rows;          // rows per block the caller planned for (igemm_colstat_rows); launch_igemm checks the kernel it picks
     int splits;           // split-K factor (1 = none); > 1 needs `slab`
     float* slab;          // [splits, M, N] fp32 partial sums
     // Gather geometry (GATHER = true): output pixel grid [NI, Ho, Wo], source grid [NI, Hi, Wi],
@@ -89,6 +96,15 @@ int igemm_plan_splits_gather(const IgemmParams& p);
 bool igemm_patch_planned(const IgemmParams& p);
 // wave-tile width (16*NT) launch_igemm will pick for a plain, unsplit EPI_LINEAR GEMM: the row-statistics slot width
 int igemm_rowstat_cols(int M, int N, int nk);
+// rows per column-statistics block of the kernel launch_igemm will run for `p` (geometry, segments and p.splits filled in):
+// 80 (halo-patch, ping-pong and persistent kernels), 64 (128-row kernel), 32 (split-K: the reduce kernel writes them),
+// 0 = this launch cannot emit them (2-D patch tiles, GEGLU)
+int igemm_colstat_rows(const IgemmParams& p, bool gather, int epilogue);
+constexpr int COLSTAT_REDUCE_ROWS = 32;
+// float index of (block, channel c, which = 0 sum / 1 sum of squares) in a column-statistics buffer of a C-channel tensor
+__host__ __device__ inline size_t cs_index(size_t block, int c, int which, int C) {
+    return ((block * (size_t)(C >> 2) + (size_t)(c >> 2)) * 2 + (size_t)which) * 4 + (size_t)(c & 3);
+}
 // partials [M, slots, 2] (sum, sum of squares over `row_len` values per row) -> out [M, 2] = (mean, rstd); fixed order
 int launch_rowstat_finalize(const float* partials, int slots, int M, int row_len, float eps, float* out, hipStream_t stream);
 // Low nibble: 0 = automatic kernel / tile choice, 1 = 128-row kernel with the widest tile,

@@ -360,6 +360,57 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmParams p)
     *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + n) = o;
 }
 
+// The same with GroupNorm column statistics of the rounded output (IgemmParams::colstat_out): a workgroup = 64 channel quads x 4
+// row lanes over one block of COLSTAT_REDUCE_ROWS rows; the row lanes' sums (rows ascending per lane) meet in LDS in lane order.
+__global__ __launch_bounds__(256) void splitk_reduce_cs_kernel(const IgemmParams p) {
+    __shared__ f32x4 s_sum[4][64], s_sq[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int nv = p.N >> 2;
+    const int nq = blockIdx.x * 64 + tx, n = nq * 4;
+    const int r0 = blockIdx.y * COLSTAT_REDUCE_ROWS;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+    if (nq < nv) {
+        const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int m = r0 + ty; m < r0 + COLSTAT_REDUCE_ROWS && m < p.M; m += 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.slab + (size_t)m * p.N + n);
+            for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(p.slab + ((size_t)s * p.M + m) * p.N + n);
+            v += bv;
+            if (p.bias2) v += *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)(m / p.rows_per_batch) * p.ldb2 + n);
+            if (p.R) {
+                const half4_t r = *reinterpret_cast<const half4_t*>(p.R + (size_t)m * p.ldr + n);
+                v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+            }
+            const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4_t*>(p.C + (size_t)m * p.ldc + n) = o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; cs[r] += f; cq[r] += f * f; }
+        }
+    }
+    s_sum[ty][tx] = cs;
+    s_sq[ty][tx] = cq;
+    __syncthreads();
+    if (ty == 0 && nq < nv) {
+        f32x4 a = s_sum[0][tx], b = s_sq[0][tx];
+#pragma unroll
+        for (int y = 1; y < 4; ++y) { a += s_sum[y][tx]; b += s_sq[y][tx]; }
+        float* dst = p.colstat_out + cs_index((size_t)blockIdx.y, n, 0, p.N);
+        *reinterpret_cast<f32x4*>(dst) = a;
+        *reinterpret_cast<f32x4*>(dst + 4) = b;
+    }
+}
+// fixed-order sum of the split-K slabs + bias / residual / rounding (+ column statistics when the caller asked for them)
+static int launch_splitk_reduce(const IgemmParams& p, hipStream_t stream) {
+    if (p.colstat_out) {
+        hipLaunchKernelGGL(splitk_reduce_cs_kernel, dim3(cdiv(p.N / 4, 64), cdiv(p.M, COLSTAT_REDUCE_ROWS)), dim3(256), 0, stream, p);
+    } else {
+        const long total = (long)p.M * (p.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+    }
+    LAVIE_HIP(hipGetLastError());
+    return 0;
+}
+
 // Split-K factor for an under-filled grid.  The 128-row tiles run 2 workgroups per CU (512 slots); a grid of
 // `blocks` tiles takes ceil(blocks*S/512) rounds of (nk/S + fixed) K-steps plus a reduce pass over S slabs.
 static int g_force_tile = 0;   // see igemm_force_tile() in igemm.h
@@ -405,6 +456,7 @@ static bool patch_fits(int M, int N, int nk, int s, int ntaps = 9) {
     const double r = (double)(M / 320) * (N / bn) * s / 256.0;
     return r / ceil(r) >= 0.85;
 }
+static int pt_bm_rows() { return 320; }      // the halo-patch kernel's tile height (igemm_patch.hip pt::BM)
 static bool patch_allowed() { const int lo = g_force_tile & 0xF; return lo == 0 || lo == 5 || lo == 8; }
 
 static int plan_splits(int M, int N, int nk, int epilogue, bool plain);
@@ -481,11 +533,7 @@ static int launch_tile(const IgemmParams& p, hipStream_t stream) {
     const int grid = cdiv(p.M, T::BM) * (p.N / T::BN);
     hipLaunchKernelGGL(kern, dim3(grid, p.splits), dim3(T::THREADS), lds, stream, p);
     LAVIE_HIP(hipGetLastError());
-    if (p.splits > 1) {
-        const long total = (long)p.M * (p.N / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
-        LAVIE_HIP(hipGetLastError());
-    }
+    if (p.splits > 1) return launch_splitk_reduce(p, stream);
     return 0;
 }
 
@@ -533,6 +581,21 @@ int igemm_rowstat_cols(int M, int N, int nk) {
     return igemm_pick_bn(M, N, 1) / 2;
 }
 
+// Mirror of launch_igemm's kernel choice (same tests in the same order): rows per column-statistics block, 0 = none.
+int igemm_colstat_rows(const IgemmParams& p, bool gather, int epilogue) {
+    if (epilogue != EPI_LINEAR || p.N % 4 != 0) return 0;
+    if (p.splits > 1) return COLSTAT_REDUCE_ROWS;                 // whatever kernel fills the slabs, the reduce kernel writes the statistics
+    const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);
+    if (p.par_ups) return 80;                                     // source-row blocks, one set per parity
+    if (!gather && ppx_plan(p, epilogue)) return 80;
+    if (gather && igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)))) {
+        // rows of a wave tile are contiguous only for tiles of whole image rows (MODE 0); 2-D tiles and the temporal mode are not
+        return (p.tframes > 0 || pt_bm_rows() % p.Wo != 0) ? 0 : 80;
+    }
+    if ((lo == 3 && p.N % 320 == 0) || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits))) return 80;
+    return igemm_pick_bn(p.M, p.N, p.splits) != 0 ? 64 : 0;
+}
+
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream) {
     LAVIE_CHECK(p.M > 0 && p.N > 0 && p.nk > 0, "igemm: empty problem M=%d N=%d nk=%d", p.M, p.N, p.nk);
     const double K = (double)p.nk * IGEMM_BK;
@@ -545,13 +608,11 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
                 "igemm: bad split-K setup (splits=%d)", p.splits);
     const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);      // 8 = automatic without the persistent kernel
     auto reduce_splits = [&]() -> int {          // fixed-order sum of the split-K slabs + bias / residual / rounding
-        if (p.splits > 1) {
-            const long total = (long)p.M * (p.N / 4);
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
-            LAVIE_HIP(hipGetLastError());
-        }
-        return 0;
+        return p.splits > 1 ? launch_splitk_reduce(p, stream) : 0;
     };
+    // the block height the caller sized the column-statistics buffer for must be the one the kernel chosen below writes
+    LAVIE_CHECK(!p.colstat_out || (epilogue == EPI_LINEAR && p.colstat_rows > 0 && p.colstat_rows == igemm_colstat_rows(p, gather, epilogue)),
+                "igemm: column statistics planned for %d-row blocks, this launch writes %d", p.colstat_rows, igemm_colstat_rows(p, gather, epilogue));
     if (p.par_ups) {             // parity form of an upsample conv: the halo-patch kernel is the only one that runs it
         LAVIE_CHECK(gather && epilogue == EPI_LINEAR && igemm_patch_eligible(p), "igemm: parity upsample conv outside the halo-patch kernel's geometry");
         if (int rc = launch_igemm_patch(p, stream)) return rc;

@@ -37,9 +37,23 @@ __device__ __forceinline__ void igemm_tile_of(int id, int m_tiles, int n_tiles, 
 // channel ncol + nt*16 + r of token mrow + mt*16.  `nwave0` = first channel of this wave's tile (GEGLU column maths).
 // `rowof(mt)` = output row of this lane in 16-row slice mt (contiguous tiles: mrow + 16 mt; the 2-D tiles of the halo-patch
 // conv kernel map slices to image rows themselves).
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4): quad swaps, then the two mirror steps; every lane ends with the
+// total (summation order fixed per lane: results are reproducible run to run)
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1, 0, 3, 2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2, 3, 0, 1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
+    return v;
+}
+
+// `cs_block` = column-statistics block of this wave's rows (p.colstat_out; -1 = none)
 template <int MT, int NT, int EPI, class RowFn>
 __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 (&acc)[NT][MT], RowFn rowof, int ncol, int nwave0,
-                                                    int lane, int split) {
+                                                    int lane, int split, int cs_block = -1) {
     // ---- folded LayerNorm of the A rows: acc <- rstd_m * (acc - mean_m * s_n); the folded bias comes in as p.bias
     if (p.ln_stats) {
         f32x4 sv[NT];
@@ -69,6 +83,10 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 
         for (int nt = 0; nt < NT; ++nt)
             bv[nt] = BIAS ? *reinterpret_cast<const f32x4*>(p.bias + ncol + nt * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI == EPI_LINEAR) {
+            const bool colstat = p.colstat_out != nullptr && cs_block >= 0;
+            f32x4 cs_s[NT], cs_q[NT];          // GroupNorm statistics of the rounded outputs: this lane's 4 channels per column tile
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { cs_s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs_q[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
             // per 16-row slice: request every optional operand first, then combine and store (measured: batching
             // the whole wave tile's loads up front buys nothing and costs ~90 VGPRs)
 #pragma unroll
@@ -98,6 +116,10 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; rs_sum += f; rs_sq += f * f; }
                     }
+                    if (colstat && m < p.M) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; cs_s[nt][r] += f; cs_q[nt][r] += f * f; }
+                    }
                 }
                 if (rowstat) {
                     // this wave's 16*NT columns of row m: fold the four 16-lane groups, one pair per (row, wave tile)
@@ -108,6 +130,18 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 
                         dst[0] = rs_sum;
                         dst[1] = rs_sq;
                     }
+                }
+            }
+            if (colstat) {
+                // fold the 16 rows a lane group holds per slice (rows ascending inside a lane, then the fixed DPP tree); lane 0 of
+                // a group stores the four sums, lane 1 the four sums of squares: one 16-byte store per column tile (cs_index layout)
+                float* dst = p.colstat_out + cs_index((size_t)cs_block, ncol, lane & 1, p.N);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x4 a, b;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a[r] = row16_sum(cs_s[nt][r]); b[r] = row16_sum(cs_q[nt][r]); }
+                    if ((lane & 15) < 2) *reinterpret_cast<f32x4*>(dst + nt * 32) = (lane & 1) ? b : a;
                 }
             }
         } else {
@@ -157,10 +191,12 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 
     }
 }
 
+// contiguous rows: the wave's rows are [mrow - (lane & 15), + 16 MT): column-statistics block = that row range / (16 MT)
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int mrow, int ncol, int nwave0,
                                                int lane, int split) {
-    igemm_epilogue_rows<MT, NT, EPI>(p, acc, [mrow](int mt) { return mrow + mt * 16; }, ncol, nwave0, lane, split);
+    igemm_epilogue_rows<MT, NT, EPI>(p, acc, [mrow](int mt) { return mrow + mt * 16; }, ncol, nwave0, lane, split,
+                                     (mrow - (lane & 15)) / (MT * 16));
 }
 
 }  // namespace lavie

@@ -526,7 +526,9 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
             const int m = m0 + wm * (MT * 16) + mt * 16 + (lane & 15);
             const int n = m / HW, rem = m - n * HW, y = rem / Wd, x = rem - y * Wd;
             return ((n * 2 * Hd + 2 * y + py) * 2 * Wd) + 2 * x + px;
-        }, n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);
+        }, n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split,
+        // column statistics: one set of source-row blocks per parity (the rows of a block lie in one frame: tiles are whole source rows)
+        (int)blockIdx.z * (p.M / 4 / (MT * 16)) + (m0 + wm * (MT * 16)) / (MT * 16));
     } else if constexpr (tmode) {
         igemm_epilogue_rows<MT, NT, EPI>(p, acc, [&](int mt) { return trow(wm * (MT * 16) + mt * 16 + (lane & 15)); },
                                          n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);

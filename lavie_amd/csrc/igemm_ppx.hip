@@ -160,6 +160,7 @@ __global__ __launch_bounds__(ppx::THREADS, 2) void igemm_ppx_kernel(const IgemmP
     constexpr bool has_fold = MODE == 2, has_res = LIN && MODE == 1;
     const bool has_bias = p.bias != nullptr;
     const bool has_rs = LIN && p.rowstat_out != nullptr;
+    const bool has_cs = LIN && p.colstat_out != nullptr;      // GroupNorm column statistics of the rounded output (igemm.h)
 
     // ---- this workgroup's tile list: ids first, first + stride, ... (count of them)
     const int n_tiles = p.N / BN;
@@ -404,16 +405,38 @@ __global__ __launch_bounds__(ppx::THREADS, 2) void igemm_ppx_kernel(const IgemmP
                 }
                 return o;
             };
+            // column statistics of one column tile: the 16-lane DPP tree of igemm_epilogue.h, then ONE 16-byte asm store (lane 0
+            // of a lane group the four sums, lane 1 the four sums of squares) so that the step's vmcnt arithmetic knows their number: NT
+            const half_t* cbase = reinterpret_cast<const half_t*>(p.colstat_out);
+            const unsigned cs_voff = (unsigned)cs_index((size_t)((m0 + wm * (MT * 16)) / (MT * 16)), n0 + ncol_l, ln & 1, p.N) * 4u;
+            auto cs_add = [&](f32x4& cs, f32x4& cq, const half4_t& o) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; cs[r] += f; cq[r] += f * f; }
+            };
+            auto cs_emit = [&](auto nt_tag, const f32x4& cs, const f32x4& cq) {
+                constexpr int nt = decltype(nt_tag)::value;
+                f32x4 a, b;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = row16_sum(cs[r]); b[r] = row16_sum(cq[r]); }
+                const f32x4 w = (ln & 1) ? b : a;
+                if ((ln & 15) < 2) asm_store_b128<nt * 128>(cs_voff, __builtin_bit_cast(u32x4, w), cbase);
+            };
             auto pair = [&](auto nt_tag) {
                 constexpr int nt = decltype(nt_tag)::value;
                 f32x4 bv0, sv0, bv1, sv1;
                 load_bs(nt, bv0, sv0);
                 load_bs(nt + 1, bv1, sv1);
+                f32x4 cs0 = zero4, cq0 = zero4, cs1 = zero4, cq1 = zero4;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const half4_t oa = finish(std::integral_constant<int, nt>{}, mt, bv0, sv0);
                     const half4_t ob = finish(std::integral_constant<int, nt + 1>{}, mt, bv1, sv1);
+                    if (has_cs) { cs_add(cs0, cq0, oa); cs_add(cs1, cq1, ob); }
                     swap_into(mt, std::integral_constant<int, nt>{}, oa, ob);
+                }
+                if (has_cs) {
+                    cs_emit(std::integral_constant<int, nt>{}, cs0, cq0);
+                    cs_emit(std::integral_constant<int, nt + 1>{}, cs1, cq1);
                 }
                 __builtin_amdgcn_sched_barrier(0);               // keep the column tiles apart: the register file is full
             };
@@ -422,12 +445,15 @@ __global__ __launch_bounds__(ppx::THREADS, 2) void igemm_ppx_kernel(const IgemmP
             if constexpr (NT == 5) {
                 f32x4 bv, sv;
                 load_bs(4, bv, sv);
+                f32x4 cs4 = zero4, cq4 = zero4;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const half4_t o = finish(std::integral_constant<int, 4>{}, mt, bv, sv);
+                    if (has_cs) cs_add(cs4, cq4, o);
                     if constexpr (DIRECT) asm_store_b64<128>(dvoff_one + mt * dstep, o, dbase);
                     else ro[mt][4] = __builtin_bit_cast(unsigned long long, o);
                 }
+                if (has_cs) cs_emit(std::integral_constant<int, 4>{}, cs4, cq4);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (has_rs) {   // this wave's 16*NT columns of each row: fold the four 16-lane groups; ONE 8-byte asm store per
@@ -605,6 +631,7 @@ __global__ __launch_bounds__(ppx::THREADS, 2) void igemm_ppx_kernel(const IgemmP
                     st_live = true;
                 }
                 if (has_rs) n_extra += MT;
+                if (has_cs) n_extra += NT;
             } else {
                 if (pm0 < 0) finish_tile(pm0, pn0, 0); // never taken: keeps the accumulators live
 #pragma unroll

@@ -12,6 +12,7 @@
 //
 // All three are HBM-bound: 16-byte vector accesses, fp32 statistics, wave/LDS reductions.
 #include "common.h"
+#include "igemm.h"
 #include "ops.h"
 #include "profile.h"
 
@@ -149,6 +150,62 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// Pass 1 + 2 replaced (round 4): the producers of x1 / x2 left per-(row block, channel) sums in their epilogues (igemm.h
+// colstat_out); one workgroup per (batch, group) folds the blocks of its statistics domain and the channels of its group — which may
+// straddle the two tensors of a skip concatenation — in a fixed order -> (mean, rstd).  Reads sizeof(tensor) / 10 .. / 40 bytes.
+struct GnFoldSrc {
+    const float* partials;
+    int C, c0;              // channels of the tensor; first channel of the tensor inside the concatenation
+    int nsets, set_blocks;  // sets of blocks, blocks per set
+    int bpd;                // blocks of one statistics domain inside a set
+};
+__global__ __launch_bounds__(256) void gn_fold_kernel(GnFoldSrc s1, GnFoldSrc s2, int groups, int cpg, float inv_count, float eps,
+                                                     float* __restrict__ stats) {
+    __shared__ float red[2][4];
+    const int idx = blockIdx.x;                 // nb * groups + g
+    const int nb = idx / groups, g = idx - nb * groups;
+    const int glo = g * cpg, ghi = glo + cpg;   // channel range of the group in the concatenation
+    float a = 0.f, b = 0.f;
+    auto fold = [&](const GnFoldSrc& s) {
+        const int lo = max(glo, s.c0) - s.c0, hi = min(ghi, s.c0 + s.C) - s.c0;      // the group's channels inside this tensor
+        if (s.partials == nullptr || hi <= lo) return;
+        const int q0 = lo >> 2, nq = ((hi + 3) >> 2) - q0;
+        const int items = s.nsets * s.bpd * nq;
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int qi = it % nq, rest = it / nq;
+            const int blk = rest % s.bpd, set = rest / s.bpd;
+            const size_t block = (size_t)set * s.set_blocks + (size_t)nb * s.bpd + blk;
+            const float* src = s.partials + cs_index(block, (q0 + qi) * 4, 0, s.C);
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = (q0 + qi) * 4 + r;
+                if (c >= lo && c < hi) { a += sv[r]; b += qv[r]; }
+            }
+        }
+    };
+    fold(s1);
+    fold(s2);
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float sa = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3], sb = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        const float mean = sa * inv_count;
+        const float var = fmaxf(sb * inv_count - mean * mean, 0.f);
+        stats[(size_t)idx * 2] = mean;
+        stats[(size_t)idx * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+// whether the producer statistics of a tensor can serve a GroupNorm over NB domains of P rows each
+static bool gn_colstat_usable(const GnColStat* cs, int C, int P) {
+    if (cs == nullptr || cs->partials == nullptr || cs->rows <= 0 || cs->C != C || cs->nsets < 1 || C % 4 != 0) return false;
+    return P % (cs->rows * cs->nsets) == 0;        // every block inside one domain (parity sets: P / nsets source rows per domain and set)
+}
+
 // y[row, :] = act((x - mean_g) * rstd_g * gamma + beta) for the slab, y is [NB*P, C1+C2] row-major.
 template <int VPT, bool SILU>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __restrict__ x1, int C1,
@@ -224,14 +281,26 @@ size_t gn_workspace_floats(int NB, int groups) { return ((size_t)GN_MAX_SLABS + 
 
 // stats_ws layout: [NB*groups*2 (mean, rstd)] [partials: NB*slabs*groups*2]
 int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* gamma,
-                      const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream) {
+                      const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream, const GnColStat* cs1,
+                      const GnColStat* cs2) {
     GnGeom g;
     const int ctot = C1 + C2;
     LAVIE_CHECK(gn_geometry(ctot, &g), "group_norm: unsupported channel count %d", ctot);
     LAVIE_CHECK(C1 % 8 == 0 && C2 % 8 == 0 && ctot % groups == 0 && groups <= GN_THREADS, "group_norm: bad channels/groups");
-    ProfileScope prof(KC_GROUPNORM, stream, 0.0, 2.0 * 3.0 * (double)NB * P * ctot);   // read, read, write
+    ProfileScope prof(KC_GROUPNORM, stream, 0.0, 2.0 * 3.0 * (double)NB * P * ctot);   // read, read, write (the two-pass definition, also when the producers' statistics save the first read)
     float* stats = ws;
     float* partials = ws + (size_t)NB * groups * 2;
+    const bool from_producers = gn_colstat_usable(cs1, C1, P) && (C2 == 0 || gn_colstat_usable(cs2, C2, P));
+    if (from_producers) {
+        auto src = [&](const GnColStat* cs, int c0) {
+            GnFoldSrc s{nullptr, 0, c0, 1, 0, 0};
+            if (cs) { s.partials = cs->partials; s.C = cs->C; s.nsets = cs->nsets; s.set_blocks = cs->set_blocks; s.bpd = P / (cs->rows * cs->nsets); }
+            return s;
+        };
+        hipLaunchKernelGGL(gn_fold_kernel, dim3(NB * groups), dim3(256), 0, stream, src(cs1, 0), src(C2 ? cs2 : nullptr, C1), groups,
+                           ctot / groups, 1.0f / ((float)P * (float)(ctot / groups)), eps, stats);
+        LAVIE_HIP(hipGetLastError());
+    } else {
     int rps;
     const int slabs = gn_slabs(P, NB, g.ty, GN_MAX_SLABS, &rps);      // NB * slabs <= GN_MAX_SLABS + NB
     const size_t lds = (size_t)g.ty * ctot * 2 * sizeof(float);
@@ -250,6 +319,7 @@ int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(total, 4)), dim3(256), 0, stream, partials, slabs, groups, total,
                        1.0f / ((float)P * (float)(ctot / groups)), eps, stats);
     LAVIE_HIP(hipGetLastError());
+    }
     int rps2;
     const int slabs2 = gn_slabs(P, NB, g.ty, 2048, &rps2);
     dim3 grid2(slabs2, NB);

@@ -11,8 +11,22 @@ namespace lavie {
 // GroupNorm (+SiLU): statistics pass (per-slab partials), finalize (mean, rstd), apply.  `ws` is
 // gn_workspace_floats(NB, groups) floats of scratch, reusable by the next call on the same stream.
 size_t gn_workspace_floats(int NB, int groups);
+// Producer-side statistics of one GroupNorm input tensor: what IgemmParams::colstat_out received from the kernel that stored the
+// tensor (igemm.h: per (row block, channel) sum and sum of squares of the rounded fp16 values).  rows == 0 / partials == nullptr =
+// none.  Parity-form upsample conv: nsets = 4 sets of set_blocks source-row blocks (a block's rows lie in ONE frame).
+struct GnColStat {
+    const float* partials = nullptr;
+    int C = 0;            // channels of the tensor
+    int rows = 0;         // rows per block
+    int nsets = 1;
+    int set_blocks = 0;   // blocks per set
+};
+// cs1 / cs2 (optional): statistics of x1 / x2 from their producers.  When both tensors have them and every block lies inside one
+// statistics domain (P %% (rows * nsets) == 0), the statistics pass over the tensor and its finalize launch are replaced by ONE small
+// fold of the partials; otherwise the two-pass path runs.
 int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* gamma,
-                      const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream);
+                      const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream,
+                      const GnColStat* cs1 = nullptr, const GnColStat* cs2 = nullptr);
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* y, int rows, int C, float eps,
                      hipStream_t stream);
 

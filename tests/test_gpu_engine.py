@@ -350,6 +350,47 @@ def test_debug_check_shared_catches_unequal_halves(small, monkeypatch):
         net.set_cfg_shared_input(False)
 
 
+def test_groupnorm_statistics_from_producers_match_the_statistics_pass(full, small):
+    """Round 4: the kernels that write a GroupNorm's input leave its per-channel sums in their epilogues (conv / GEMM epilogue, the
+    persistent GEMM's finish pass, the split-K reduce, the parity-form upsample conv) and the GroupNorm folds those instead of reading
+    the tensor for statistics (lavie_debug_fused_mask bit 5).  Both paths sum the same rounded fp16 values in fp32, in different
+    orders: the forward must agree to well below the fp16 resolution of the activations, at the production shape (every producer
+    kernel the planner picks there, skip concatenations with straddling groups, per-frame and per-video domains, the shared CFG
+    prefix) and at the reduced width (ragged tiles: the fallback to the statistics pass)."""
+    import bench
+    from lavie_amd import _lib
+    lib = _lib.load()
+    net, _ = full
+    pe, ne, lat = bench.synth_inputs(0, "cpu")
+    ctx = torch.cat([ne, pe]).half().cuda()
+    x = torch.cat([lat, lat]).half().cuda()
+    try:
+        outs = {}
+        for shared in (False, True):
+            cc = net.cache_context(ctx)
+            net.set_cfg_shared_input(shared)
+            for mask in (~8 & ~32, ~8):
+                _lib.check(lib.lavie_debug_fused_mask(mask), "lavie_debug_fused_mask")
+                outs[(shared, mask)] = net(x, 500, encoder_hidden_states=cc).sample.clone()
+            assert torch.equal(outs[(shared, ~8)], net(x, 500, encoder_hidden_states=cc).sample)      # fixed summation order
+            assert rel_l2(outs[(shared, ~8)], outs[(shared, ~8 & ~32)]) < 3e-4, (shared, rel_l2(outs[(shared, ~8)], outs[(shared, ~8 & ~32)]))
+            net.set_cfg_shared_input(False)
+            net.cache_context(None)
+        snet, _ = small
+        g = torch.Generator().manual_seed(9)
+        xs = torch.randn(2, 4, 4, 8, 8, generator=g).half().cuda()
+        cs = torch.randn(2, 77, 128, generator=g).half().cuda()
+        ys = {}
+        for mask in (~8 & ~32, ~8):
+            _lib.check(lib.lavie_debug_fused_mask(mask), "lavie_debug_fused_mask")
+            ys[mask] = snet(xs, 300, encoder_hidden_states=cs).sample.clone()
+        assert rel_l2(ys[~8], ys[~8 & ~32]) < 3e-4
+    finally:
+        lib.lavie_debug_fused_mask(~8)
+        net.set_cfg_shared_input(False)
+        net.cache_context(None)
+
+
 def test_three_ddpm_steps_golden(full):
     """VideoGenPipeline loop (CFG + fused DDPM step) for 3 steps against the reference-UNet trajectory."""
     from lavie_amd.pipeline_videogen import VideoGenPipeline
