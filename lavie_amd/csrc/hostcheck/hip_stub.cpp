@@ -5,6 +5,7 @@
 // hipMemcpy* bounds-checked by ASan against the exact-size heap blocks behind it.  Never linked into liblavie_hip.so.
 #include <hip/hip_runtime_api.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -49,11 +50,12 @@ hipError_t __hipPopCallConfiguration(dim3* grid, dim3* block, size_t* shmem, hip
     return hipSuccess;
 }
 static long g_launches = 0;
-hipError_t hipLaunchKernel(const void*, dim3 grid, dim3 block, void**, size_t shmem, hipStream_t) {
+hipError_t hipLaunchKernel(const void* f, dim3 grid, dim3 block, void**, size_t shmem, hipStream_t) {
     // the launch geometry itself is host logic worth checking
     if (grid.x == 0 || grid.y == 0 || grid.z == 0 || block.x * block.y * block.z == 0 || block.x * block.y * block.z > 1024 ||
         shmem > 160 * 1024) abort();
     ++g_launches;
+    if (getenv("LAVIE_HOSTCHECK_TRACE")) fprintf(stderr, "launch %p\n", f);
     return hipSuccess;
 }
 hipError_t hipExtLaunchKernel(const void* f, dim3 grid, dim3 block, void** args, size_t shmem, hipStream_t s, hipEvent_t, hipEvent_t, int) {
