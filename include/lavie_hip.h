@@ -211,6 +211,10 @@ int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long lo
  * producing kernel's epilogue instead of a statistics pass (round 4).  Default ~8 (every bit but 3).  mask & ~0x37 == 0 with
  * bits 0-2, 4, 5 clear = the one-GEMM-per-launch path of round 2. */
 int lavie_debug_fused_mask(int mask);
+/* Test hook: GroupNorm launches so far (process-wide) that took their statistics from the producers' epilogues.  Bit 6 of the mask
+ * above makes every such launch ALSO run the statistics pass and compare the two on the host (synchronises; an error names the
+ * first (batch, group) that differs). */
+long long lavie_debug_gn_producer_count(void);
 int lavie_debug_temporal_block_dump(float* buf);   /* development aid: device buffer of 100 * 64 floats, or NULL */
 int lavie_debug_rowfuse_stamps(unsigned long long* buf);   /* stamp build (variant 7): device buffer of 64 u64, or NULL */
 int lavie_debug_rowfuse_variant(int v);   /* tuning: LDS read-ahead depth of the fused kernels (0 = default) */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "lavie_debug_force_tile": (c_int, [c_int]),
     "lavie_debug_force_splits": (c_int, [c_int]),
     "lavie_debug_fused_mask": (c_int, [c_int]),
+    "lavie_debug_gn_producer_count": (c_ll, []),
     "lavie_debug_temporal_block_dump": (c_int, [c_void_p]),
     "lavie_debug_rowfuse_variant": (c_int, [c_int]),
     "lavie_debug_rowfuse_stamps": (c_int, [c_void_p]),

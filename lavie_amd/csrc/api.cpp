@@ -307,6 +307,7 @@ int lavie_debug_ppx_stamps(unsigned long long* out256) {
     LAVIE_CHECK(out256, "ppx_stamps: null output");
     return igemm_ppx_read_stamps(out256);
 }
+long long lavie_debug_gn_producer_count(void) { return (long long)lavie::gn_producer_count(); }
 
 int lavie_debug_patch_stamps(unsigned long long* out128) {
     LAVIE_CHECK(out128, "patch_stamps: null output");

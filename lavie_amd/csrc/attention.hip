@@ -746,7 +746,10 @@ static int launch_att_dma(const AttnParams& p, hipStream_t stream) {
     // (head dims 128 / 160 keep it: they are MFMA-bound, and the four initialiser registers per query tile would push the
     // 32-row instantiations past 256 VGPRs = from two waves per SIMD to one)
     constexpr bool V2_OK = NCH <= 10;
-    auto kern = (g_force_qt == 0x60 || !V2_OK) ? attention_dma_kernel<NCH, QT, NBUF, LSUM, SC, false>
+    // (and the 77-key text cross-attention at head dim 40: two key tiles, the first of which always takes the rescale branch —
+    // measured 41 -> 46 us at level 0, tools/ab_attn_v2.py)
+    const bool short_keys = NCH == 5 && p.Lk <= 2 * ATT_KEYS;
+    auto kern = (g_force_qt == 0x60 || !V2_OK || short_keys) ? attention_dma_kernel<NCH, QT, NBUF, LSUM, SC, false>
                                                 : attention_dma_kernel<NCH, QT, NBUF, LSUM, SC, V2_OK>;
     if (int rc = ensure_dynamic_lds((const void*)kern, lds)) return rc;
     dim3 grid(cdiv(p.Lq, 4 * QT * 16), p.heads, p.NBq);

@@ -16,6 +16,9 @@
 #include "ops.h"
 #include "profile.h"
 
+#include <math.h>
+#include <vector>
+
 namespace lavie {
 
 constexpr int GN_THREADS = 256;
@@ -171,18 +174,31 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(GnFoldSrc s1, GnFoldSrc s2
         if (s.partials == nullptr || hi <= lo) return;
         const int q0 = lo >> 2, nq = ((hi + 3) >> 2) - q0;
         const int items = s.nsets * s.bpd * nq;
-        for (int it = threadIdx.x; it < items; it += 256) {
-            const int qi = it % nq, rest = it / nq;
-            const int blk = rest % s.bpd, set = rest / s.bpd;
-            const size_t block = (size_t)set * s.set_blocks + (size_t)nb * s.bpd + blk;
-            const float* src = s.partials + cs_index(block, (q0 + qi) * 4, 0, s.C);
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(src);
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(src + 4);
+        // four items per thread in flight (all loads, then the adds in ascending item order): one dependent L2 round trip per item
+        // made this kernel 5-6 us for the level-0 tensors (64 workgroups, 8 items per thread)
+        constexpr int FU = 4;
+        for (int it0 = threadIdx.x; it0 < items; it0 += 256 * FU) {
+            f32x4 sv[FU], qv[FU];
+            int cq[FU];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = (q0 + qi) * 4 + r;
-                if (c >= lo && c < hi) { a += sv[r]; b += qv[r]; }
+            for (int u = 0; u < FU; ++u) {
+                const int it = it0 + u * 256;
+                const int itc = it < items ? it : items - 1;
+                const int qi = itc % nq, rest = itc / nq;
+                const int blk = rest % s.bpd, set = rest / s.bpd;
+                const size_t block = (size_t)set * s.set_blocks + (size_t)nb * s.bpd + blk;
+                const float* src = s.partials + cs_index(block, (q0 + qi) * 4, 0, s.C);
+                sv[u] = *reinterpret_cast<const f32x4*>(src);
+                qv[u] = *reinterpret_cast<const f32x4*>(src + 4);
+                cq[u] = it < items ? (q0 + qi) * 4 : -8;        // -8: every channel of the quad falls outside [lo, hi)
             }
+#pragma unroll
+            for (int u = 0; u < FU; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = cq[u] + r;
+                    if (c >= lo && c < hi) { a += sv[u][r]; b += qv[u][r]; }
+                }
         }
     };
     fold(s1);
@@ -200,6 +216,8 @@ __global__ __launch_bounds__(256) void gn_fold_kernel(GnFoldSrc s1, GnFoldSrc s2
     }
 }
 
+static long g_gn_from_producers = 0;      // GroupNorm launches that took their statistics from the producers (lavie_debug_gn_producer_count)
+long gn_producer_count() { return g_gn_from_producers; }
 // whether the producer statistics of a tensor can serve a GroupNorm over NB domains of P rows each
 static bool gn_colstat_usable(const GnColStat* cs, int C, int P) {
     if (cs == nullptr || cs->partials == nullptr || cs->rows <= 0 || cs->C != C || cs->nsets < 1 || C % 4 != 0) return false;
@@ -291,6 +309,12 @@ int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB
     float* stats = ws;
     float* partials = ws + (size_t)NB * groups * 2;
     const bool from_producers = gn_colstat_usable(cs1, C1, P) && (C2 == 0 || gn_colstat_usable(cs2, C2, P));
+    // lavie_debug_fused_mask bit 6 (debug, synchronises): both paths run and every (mean, rstd) pair of the fold is compared with the
+    // statistics pass on the host — the direct check of each producer's epilogue sums (tests/test_gpu_engine.py)
+    if (from_producers) ++g_gn_from_producers;
+    const bool verify = from_producers && (fused_mask() & 64);
+    float* fold_stats = stats;
+    if (verify) LAVIE_HIP(hipMalloc(&fold_stats, (size_t)NB * groups * 2 * sizeof(float)));
     if (from_producers) {
         auto src = [&](const GnColStat* cs, int c0) {
             GnFoldSrc s{nullptr, 0, c0, 1, 0, 0};
@@ -298,9 +322,10 @@ int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB
             return s;
         };
         hipLaunchKernelGGL(gn_fold_kernel, dim3(NB * groups), dim3(256), 0, stream, src(cs1, 0), src(C2 ? cs2 : nullptr, C1), groups,
-                           ctot / groups, 1.0f / ((float)P * (float)(ctot / groups)), eps, stats);
+                           ctot / groups, 1.0f / ((float)P * (float)(ctot / groups)), eps, fold_stats);
         LAVIE_HIP(hipGetLastError());
-    } else {
+    }
+    if (!from_producers || verify) {
     int rps;
     const int slabs = gn_slabs(P, NB, g.ty, GN_MAX_SLABS, &rps);      // NB * slabs <= GN_MAX_SLABS + NB
     const size_t lds = (size_t)g.ty * ctot * 2 * sizeof(float);
@@ -319,6 +344,20 @@ int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(total, 4)), dim3(256), 0, stream, partials, slabs, groups, total,
                        1.0f / ((float)P * (float)(ctot / groups)), eps, stats);
     LAVIE_HIP(hipGetLastError());
+    }
+    if (verify) {
+        std::vector<float> a((size_t)NB * groups * 2), b(a.size());
+        LAVIE_HIP(hipStreamSynchronize(stream));
+        LAVIE_HIP(hipMemcpy(a.data(), fold_stats, a.size() * sizeof(float), hipMemcpyDeviceToHost));
+        LAVIE_HIP(hipMemcpy(b.data(), stats, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(fold_stats);
+        for (size_t i = 0; i < a.size(); i += 2) {
+            // mean: absolute against the group's spread 1 / rstd; rstd: relative.  Both paths sum the same fp16 values in fp32.
+            const float dm = fabsf(a[i] - b[i]) * b[i + 1], dr = fabsf(a[i + 1] - b[i + 1]) / b[i + 1];
+            LAVIE_CHECK(dm < 1e-3f && dr < 1e-3f && a[i] == a[i] && a[i + 1] == a[i + 1],
+                        "group_norm: producer statistics differ from the statistics pass at (batch, group) %zu of %d x %d (C %d+%d, P %d): mean %g vs %g, "
+                        "rstd %g vs %g", i / 2, NB, groups, C1, C2, P, a[i], b[i], a[i + 1], b[i + 1]);
+        }
     }
     int rps2;
     const int slabs2 = gn_slabs(P, NB, g.ty, 2048, &rps2);

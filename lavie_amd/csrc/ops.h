@@ -27,6 +27,7 @@ struct GnColStat {
 int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* gamma,
                       const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream,
                       const GnColStat* cs1 = nullptr, const GnColStat* cs2 = nullptr);
+long gn_producer_count();     // GroupNorm launches so far whose statistics came from the producers' epilogues (test hook)
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* y, int rows, int C, float eps,
                      hipStream_t stream);
 
