@@ -417,7 +417,7 @@ def main():
     pipe = VideoGenPipeline(unet=net, scheduler=DDPMScheduler(beta_start=1e-4, beta_end=0.02, beta_schedule="linear"))
     pipe.cfg_shared_prefix = not args.no_cfg_shared_prefix
     if args.no_upsample_parity:
-        _lib.check(lib.lavie_debug_fused_mask(~8 & ~16), "lavie_debug_fused_mask")
+        _lib.check(lib.lavie_debug_fused_mask(_lib.FUSED_DEFAULT & ~16), "lavie_debug_fused_mask")
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
@@ -516,7 +516,7 @@ def main():
         nv = min(args.steps, 2)
         was_shared = pipe.cfg_shared_prefix
         pipe.cfg_shared_prefix = False
-        _lib.check(lib.lavie_debug_fused_mask(~8 & ~16), "lavie_debug_fused_mask")
+        _lib.check(lib.lavie_debug_fused_mask(_lib.FUSED_DEFAULT & ~16), "lavie_debug_fused_mask")
         net.prepare(2, FRAMES, LAT_H, LAT_W, CTX_LEN)
         one_video(0)
         barrier()
@@ -526,7 +526,7 @@ def main():
         barrier()
         el3 = time.perf_counter() - t3
         pipe.cfg_shared_prefix = was_shared
-        _lib.check(lib.lavie_debug_fused_mask(~8 & ~16 if args.no_upsample_parity else ~8), "lavie_debug_fused_mask")
+        _lib.check(lib.lavie_debug_fused_mask(_lib.FUSED_DEFAULT & ~16 if args.no_upsample_parity else _lib.FUSED_DEFAULT), "lavie_debug_fused_mask")
         net.prepare(2, FRAMES, LAT_H, LAT_W, CTX_LEN)
         if world > 1:
             tt = torch.tensor([el3], dtype=torch.float64, device=device)

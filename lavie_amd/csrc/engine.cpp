@@ -23,7 +23,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 static unsigned long g_debug_epoch = 0;
-static int g_fused_mask = ~8;         // bit 0: fused feed-forward, 1: fused temporal sub-block, 2: fused text cross-attention, 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (off), 4: parity form of the upsample convs, 5: GroupNorm statistics from the producers' epilogues (A/B switches)
+static int g_fused_mask = 0x37;        // bit 0: fused feed-forward, 1: fused temporal sub-block, 2: fused text cross-attention, 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (off), 4: parity form of the upsample convs, 5: GroupNorm statistics from the producers' epilogues (A/B switches); 6: debug verification of those statistics against the statistics pass (off)
 void set_fused_mask(int m) { g_fused_mask = m; }
 int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
@@ -649,6 +649,7 @@ static void colstat_plan(IgemmParams& p, bool gather, float* buf, GnColStat* out
     out->partials = buf;
     out->C = p.N;
     out->rows = rows;
+    out->span = igemm_colstat_span(p, gather, rows);
     if (p.par_ups && p.splits == 1) { out->nsets = 4; out->set_blocks = p.M / 4 / rows; }     // source-row blocks per output parity
     else { out->nsets = 1; out->set_blocks = cdiv(p.M, rows); }                               // (split-K: the reduce kernel walks output rows)
 }

@@ -100,6 +100,10 @@ int igemm_rowstat_cols(int M, int N, int nk);
 // 80 (halo-patch, ping-pong and persistent kernels), 64 (128-row kernel), 32 (split-K: the reduce kernel writes them),
 // 0 = this launch cannot emit them (2-D patch tiles, GEGLU)
 int igemm_colstat_rows(const IgemmParams& p, bool gather, int epilogue);
+// ... and the aligned run of output rows inside which the rows of one such block lie (GnColStat::span): the block height itself
+// for kernels whose wave tiles are contiguous rows; one frame for the halo-patch kernel's 2-D tiles and for the parity-form
+// upsample conv; one video for its temporal-conv tiles (call after igemm_colstat_rows returned > 0)
+int igemm_colstat_span(const IgemmParams& p, bool gather, int rows);
 constexpr int COLSTAT_REDUCE_ROWS = 32;
 // float index of (block, channel c, which = 0 sum / 1 sum of squares) in a column-statistics buffer of a C-channel tensor
 __host__ __device__ inline size_t cs_index(size_t block, int c, int which, int C) {

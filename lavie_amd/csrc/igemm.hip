@@ -589,11 +589,28 @@ int igemm_colstat_rows(const IgemmParams& p, bool gather, int epilogue) {
     if (p.par_ups) return 80;                                     // source-row blocks, one set per parity
     if (!gather && ppx_plan(p, epilogue)) return 80;
     if (gather && igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)))) {
-        // rows of a wave tile are contiguous only for tiles of whole image rows (MODE 0); 2-D tiles and the temporal mode are not
-        return (p.tframes > 0 || pt_bm_rows() % p.Wo != 0) ? 0 : 80;
+        // tiles of whole image rows (MODE 0): a wave tile = 80 contiguous rows.  2-D tiles (MODE 1) and temporal-conv tiles (MODE 2):
+        // 80 scattered rows of one frame / one video, numbered tile * 4 + wave (igemm_colstat_span)
+        return 80;
     }
     if ((lo == 3 && p.N % 320 == 0) || ((lo == 0 || lo == 6) && pp_fits(p.M, p.N, p.nk, p.splits))) return 80;
     return igemm_pick_bn(p.M, p.N, p.splits) != 0 ? 64 : 0;
+}
+
+int igemm_colstat_span(const IgemmParams& p, bool gather, int rows) {
+    if (p.splits > 1) return rows;                                 // the reduce kernel walks contiguous output rows
+    const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);
+    const bool patch = gather && igemm_patch_eligible(p) &&
+                       (p.par_ups || lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)));
+    if (!patch) return rows;
+    if (p.par_ups) {                                               // 80 source rows -> their 4 output parities, one set each
+        const int hw = p.Hi * p.Wi;
+        return 4 * (hw % rows == 0 ? hw : (rows % hw == 0 ? rows : 320));
+    }
+    if (p.tframes > 0) return p.tframes * p.tpix;                  // a tile = every frame of 320 / F pixels of ONE video
+    if (pt_bm_rows() % p.Wo != 0) return p.Ho * p.Wo;              // 2-D tile: 10 rows x 32 columns of ONE frame
+    const int hw = p.Ho * p.Wo;                                    // whole image rows: contiguous; frames smaller than a wave tile nest
+    return hw % rows == 0 ? rows : (rows % hw == 0 ? rows : 320);
 }
 
 int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t stream) {

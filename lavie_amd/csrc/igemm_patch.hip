@@ -530,12 +530,14 @@ __global__ __launch_bounds__(pt::THREADS, 2) void igemm_patch_kernel(const Igemm
         // column statistics: one set of source-row blocks per parity (the rows of a block lie in one frame: tiles are whole source rows)
         (int)blockIdx.z * (p.M / 4 / (MT * 16)) + (m0 + wm * (MT * 16)) / (MT * 16));
     } else if constexpr (tmode) {
+        // column statistics: block = tile * 4 + wave row (80 rows of ONE video: valid for video-domain GroupNorms, GnColStat::span)
         igemm_epilogue_rows<MT, NT, EPI>(p, acc, [&](int mt) { return trow(wm * (MT * 16) + mt * 16 + (lane & 15)); },
-                                         n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);
+                                         n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split, tile_m * 4 + wm);
     } else if constexpr (t2) {       // slice mt of wave row wm = 16 pixels of image row ty0 + (5 wm + mt) / 2, columns tx0 + 16 ((5 wm + mt) & 1) ..
         const int rbase = (frame0 * Hd + ty0) * Wd + tx0 + (lane & 15);
+        // column statistics: block = tile * 4 + wave row (80 pixels of ONE frame; the tiles of a frame are consecutive)
         igemm_epilogue_rows<MT, NT, EPI>(p, acc, [=](int mt) { const int r16 = 5 * wm + mt; return rbase + (r16 >> 1) * Wd + (r16 & 1) * 16; },
-                                         n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split);
+                                         n0 + wn * (NT * 16) + (lane >> 4) * 4, n0 + wn * (NT * 16), lane, split, tile_m * 4 + wm);
     } else {
         igemm_epilogue<MT, NT, EPI>(p, acc, m0 + wm * (MT * 16) + (lane & 15), n0 + wn * (NT * 16) + (lane >> 4) * 4,
                                     n0 + wn * (NT * 16), lane, split);

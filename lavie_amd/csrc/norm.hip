@@ -221,7 +221,9 @@ long gn_producer_count() { return g_gn_from_producers; }
 // whether the producer statistics of a tensor can serve a GroupNorm over NB domains of P rows each
 static bool gn_colstat_usable(const GnColStat* cs, int C, int P) {
     if (cs == nullptr || cs->partials == nullptr || cs->rows <= 0 || cs->C != C || cs->nsets < 1 || C % 4 != 0) return false;
-    return P % (cs->rows * cs->nsets) == 0;        // every block inside one domain (parity sets: P / nsets source rows per domain and set)
+    // every block inside one domain: the domain is a whole number of spans and of blocks (parity sets: P / nsets source rows per
+    // domain and set)
+    return cs->span > 0 && P % cs->span == 0 && P % (cs->rows * cs->nsets) == 0;
 }
 
 // y[row, :] = act((x - mean_g) * rstd_g * gamma + beta) for the slab, y is [NB*P, C1+C2] row-major.

@@ -20,6 +20,8 @@ struct GnColStat {
     int rows = 0;         // rows per block
     int nsets = 1;
     int set_blocks = 0;   // blocks per set
+    int span = 0;         // the rows of a block lie inside ONE aligned run of `span` tensor rows (contiguous blocks: = rows; 2-D conv
+                          // tiles: one frame; temporal-conv tiles: one video): a statistics domain must be a whole number of spans
 };
 // cs1 / cs2 (optional): statistics of x1 / x2 from their producers.  When both tensors have them and every block lies inside one
 // statistics domain (P %% (rows * nsets) == 0), the statistics pass over the tensor and its finalize launch are replaced by ONE small

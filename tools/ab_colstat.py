@@ -22,7 +22,7 @@ def main():
     ctx = net.cache_context(torch.cat([ne, pe]).half().contiguous())
     x2 = torch.cat([lat, lat]).half().contiguous()
     net.set_cfg_shared_input(True)
-    masks = (~8 & ~32, ~8)
+    masks = (_lib.FUSED_DEFAULT & ~32, _lib.FUSED_DEFAULT)
     outs = {}
     for mask in masks:
         lib.lavie_debug_fused_mask(mask)
@@ -50,7 +50,7 @@ def main():
         net(x2, 500, encoder_hidden_states=ctx)
         rows = bench.profile_end(lib)
         print(("stats pass    " if mask == masks[0] else "from producers"), " ".join(f"{r['name'].split('_')[0]}={r['ms']:.3f}({r['launches']})" for r in rows if r["launches"]), flush=True)
-    lib.lavie_debug_fused_mask(~8)
+    lib.lavie_debug_fused_mask(_lib.FUSED_DEFAULT)
     net.set_cfg_shared_input(False)
 
 

@@ -44,7 +44,7 @@ def main():
             torch.cuda.synchronize()
             line += f"  mask {mask}: {s.elapsed_time(e) / 10:7.3f} ms"
         print(line, flush=True)
-    lib.lavie_debug_fused_mask(~8)
+    lib.lavie_debug_fused_mask(_lib.FUSED_DEFAULT)
 
 
 if __name__ == "__main__":
