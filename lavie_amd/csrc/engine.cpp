@@ -897,12 +897,15 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     const bool ff_first = cfg_.ff_before_temporal != 0;
     // row-resident fused sub-blocks (rowfuse.hip), base block order only: they take their LayerNorm statistics from the rows
     // they hold, so their producers emit none
-    const bool fused_ff = t.ff_img != nullptr && !ff_first && (fused_mask() & 1);
+    // (round 4) the feed-forward and text cross-attention kernels do not depend on the block order: in the interpolation order the
+    // feed-forward kernel ALSO writes the (mean, rstd) rows its consumer, the LayerNorm-folded temporal qkv projection, needs
+    const bool fused_ff = t.ff_img != nullptr && (fused_mask() & 1) && (!ff_first || fold);
     const bool fused_t = t.tb_img != nullptr && !ff_first && c.F == 16 && (fused_mask() & 2);
     // attn1.to_out -> + residual -> norm2 -> attn2 -> to_out -> + residual in one kernel: needs this context's K / V image, and
-    // (it emits no row statistics) the fused temporal kernel behind it
-    const bool fused_x = t.xb_tmpl != nullptr && kv_cached && xb_bound_ && xb_img_[ti] != nullptr && fused_t && !t.attn1_cross &&
-                         (fused_mask() & 4) && cross_block_supported(C, heads, c.ctx_len, c.F * D);
+    // (it emits no row statistics) behind it a kernel that takes its LayerNorm statistics from the rows it holds: the fused temporal
+    // kernel in the base order, the fused feed-forward kernel in the interpolation order
+    const bool fused_x = t.xb_tmpl != nullptr && kv_cached && xb_bound_ && xb_img_[ti] != nullptr && (ff_first ? fused_ff : fused_t) &&
+                         !t.attn1_cross && (fused_mask() & 4) && cross_block_supported(C, heads, c.ctx_len, c.F * D);
     LnFold lf{nullptr, nullptr};
     RowStat rsd{nullptr, nullptr, C / igemm_rowstat_cols(T, C, C / IGEMM_BK)};
     const RowStat* rowstat = nullptr;
@@ -983,7 +986,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = c.ctx_len; a.heads = heads; a.dh = dh; a.kv_batch_div = c.F; a.scale = scale;
         RUN(launch_attention(a, c.s));
     }
-    RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, fused_t ? nullptr : rowstat));
+    RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, (ff_first ? fused_ff : fused_t) ? nullptr : rowstat));
     }
 
     // base block order: temporal -> feed-forward (attention.py:548-560); interpolation block: feed-forward -> temporal
@@ -1020,7 +1023,10 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     auto feed_forward = [&]() -> int {
         // GEGLU feed-forward (attention.py:558)
         if (fused_ff) {        // norm3 -> ff1 -> GEGLU -> ff2 -> + residual in ONE kernel, in place on the residual stream
-            LAUNCH(launch_geglu_mlp(tx, tx, T, C, t.ff_img, t.ff_b1img, t.ln3.g, t.ln3.b, t.ff2.b, 1e-5f, c.s));
+            // interpolation order: norm_temp consumes this output; the kernel writes its (mean, rstd) rows where ff2's epilogue +
+            // rowstat_finalize would have put them
+            LAUNCH(launch_geglu_mlp(tx, tx, T, C, t.ff_img, t.ff_b1img, t.ln3.g, t.ln3.b, t.ff2.b, 1e-5f, c.s,
+                                    ff_first ? const_cast<float*>(lf.stats) : nullptr));
             return 0;
         }
         if (fold && !fused_t) {       // (the fused temporal kernel emits no row statistics: explicit LayerNorm behind it)

@@ -69,7 +69,11 @@ constexpr int MAX_WG = 256;                             // one workgroup per CU
 // 8-byte global load the compiler does not track (cdna_hip_programming.md §5.7): counted and waited for by hand
 template <int IMM>
 __device__ __forceinline__ void asm_load_b64(unsigned long long& dst, unsigned voff, const void* sbase) {
-    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+    // s_nop 4: the scalar base may have been written by a VALU instruction just before the statement (hipcc spills SGPRs to VGPR
+    // lanes and reloads them with v_readlane right in front of their use); a VMEM instruction that reads such an SGPR as its base
+    // needs 5 wait states, and hipcc pads nothing inside an asm statement (guide 5.7 item 2).  Round 4: exactly that reload in
+    // front of the column-statistics store of igemm_ppx_kernel<0, 4, 1, 0> sent the store to a stale base (memory aperture fault).
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
 }
 // stamp build (ABL 3): per-wave cycle sums of workgroup 0, [wave][32]: segments 0..9 of ordinary K-tile steps, 16..25 of
 // the steps that carry an epilogue, [10] K-tile steps, [11] epilogue steps, [12] whole loop.  Segments: 0 DMA batch,
@@ -82,11 +86,11 @@ template <int IMM>
 __device__ __forceinline__ void asm_store_b128(unsigned voff, u32x4 v, const void* sbase) {
     // s_nop 1: a store of more than 8 bytes must not have its data registers overwritten in the next wait state, and
     // hipcc's hazard recognizer does not look inside an asm statement (cdna_hip_programming.md §5.7)
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");     // s_nop 4: see asm_load_b64
 }
 template <int IMM>
 __device__ __forceinline__ void asm_store_b64(unsigned voff, half4_t v, const void* sbase) {
-    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
 }
 }  // namespace ppx
 

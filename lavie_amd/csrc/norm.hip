@@ -315,8 +315,9 @@ int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB
     // statistics pass on the host — the direct check of each producer's epilogue sums (tests/test_gpu_engine.py)
     if (from_producers) ++g_gn_from_producers;
     const bool verify = from_producers && (fused_mask() & 64);
-    float* fold_stats = stats;
-    if (verify) LAVIE_HIP(hipMalloc(&fold_stats, (size_t)NB * groups * 2 * sizeof(float)));
+    float* const fold_stats = stats;           // what the apply pass reads, in both modes
+    float* pass_stats = stats;                 // verify: the statistics pass writes a scratch copy instead
+    if (verify) LAVIE_HIP(hipMalloc(&pass_stats, (size_t)NB * groups * 2 * sizeof(float)));
     if (from_producers) {
         auto src = [&](const GnColStat* cs, int c0) {
             GnFoldSrc s{nullptr, 0, c0, 1, 0, 0};
@@ -344,15 +345,15 @@ int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB
     LAVIE_HIP(hipGetLastError());
     const int total = NB * groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(total, 4)), dim3(256), 0, stream, partials, slabs, groups, total,
-                       1.0f / ((float)P * (float)(ctot / groups)), eps, stats);
+                       1.0f / ((float)P * (float)(ctot / groups)), eps, pass_stats);
     LAVIE_HIP(hipGetLastError());
     }
     if (verify) {
         std::vector<float> a((size_t)NB * groups * 2), b(a.size());
         LAVIE_HIP(hipStreamSynchronize(stream));
         LAVIE_HIP(hipMemcpy(a.data(), fold_stats, a.size() * sizeof(float), hipMemcpyDeviceToHost));
-        LAVIE_HIP(hipMemcpy(b.data(), stats, b.size() * sizeof(float), hipMemcpyDeviceToHost));
-        (void)hipFree(fold_stats);
+        LAVIE_HIP(hipMemcpy(b.data(), pass_stats, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+        (void)hipFree(pass_stats);
         for (size_t i = 0; i < a.size(); i += 2) {
             // mean: absolute against the group's spread 1 / rstd; rstd: relative.  Both paths sum the same fp16 values in fp32.
             const float dm = fabsf(a[i] - b[i]) * b[i + 1], dr = fabsf(a[i + 1] - b[i + 1]) / b[i + 1];

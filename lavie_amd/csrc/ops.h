@@ -113,8 +113,9 @@ size_t geglu_mlp_image_bytes(int C);
 size_t geglu_mlp_bias_floats(int C);
 int pack_geglu_mlp(const half_t* w1, const half_t* b1, const half_t* w2, int C, half_t* img, float* b1img, hipStream_t stream);
 // y = x + W2 (h * gelu(g)) + b2, (h, g) = W1 LN(x) + b1; y may alias x
+// stats_out (optional, [M, 2]): (mean, rstd) of every output row for a LayerNorm-folded GEMM that consumes y (eps as the input norm's)
 int launch_geglu_mlp(const half_t* x, half_t* y, int M, int C, const half_t* img, const float* b1img, const float* gamma,
-                     const float* beta, const float* b2, float eps, hipStream_t stream);
+                     const float* beta, const float* b2, float eps, hipStream_t stream, float* stats_out = nullptr);
 
 // x' = x + to_out(attn_temp(LN(x))) for clips of exactly 16 frames, rows in (b f) d order; y may alias x
 void temporal_block_set_debug(float* buf);   // development aid: register-tile dump of workgroup 0 (nullptr = off)

@@ -75,6 +75,9 @@ struct GegluMlpParams {
     int tiles;               // 16-row tiles = ceil(M / 16), dealt to the workgroups in contiguous, near-equal runs
     float eps;
     unsigned long long* stamps;   // stamp build only: [8 waves][8] cycle sums of workgroup 0
+    float* stats_out;        // optional [M, 2]: (mean, rstd) of every OUTPUT row (of its rounded fp16 values): what a LayerNorm-folded
+                             // GEMM that consumes y needs (IgemmParams::ln_stats) — the interpolation block's norm_temp follows the
+                             // feed-forward (interpolation/models/attention.py:592-604); nullptr = not written
 };
 
 template <int C, int PF, int ABL = 0>
@@ -266,9 +269,23 @@ __global__ __launch_bounds__(rf::THREADS, 2) void geglu_mlp_kernel(const GegluMl
         // ---- x' = residual registers, one rounding
         if (active && row < p.M) {
             half_t* yr = p.y + (size_t)row * C + 4 * q;
+            float osum = 0.f, osq = 0.f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                *reinterpret_cast<half4_t*>(yr + 16 * t) = (half4_t){(half_t)R[t][0], (half_t)R[t][1], (half_t)R[t][2], (half_t)R[t][3]};
+            for (int t = 0; t < NT; ++t) {
+                const half4_t o = {(half_t)R[t][0], (half_t)R[t][1], (half_t)R[t][2], (half_t)R[t][3]};
+                *reinterpret_cast<half4_t*>(yr + 16 * t) = o;
+                if (p.stats_out) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; osum += f; osq += f * f; }
+                }
+            }
+            if (p.stats_out) {        // the row's 320 channels sit in the four lanes that share `col` (wave-uniform branch)
+                osum += __shfl_xor(osum, 16, 64); osq += __shfl_xor(osq, 16, 64);
+                osum += __shfl_xor(osum, 32, 64); osq += __shfl_xor(osq, 32, 64);
+                const float omean = osum * (1.0f / C);
+                const float orstd = rsqrtf(fmaxf(osq * (1.0f / C) - omean * omean, 0.f) + p.eps);      // rowstat_finalize_kernel's formula
+                if (q == 0) *reinterpret_cast<float2*>(p.stats_out + (size_t)row * 2) = make_float2(omean, orstd);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -303,14 +320,14 @@ static int launch_geglu_mlp_t(const GegluMlpParams& p, hipStream_t stream, const
 }
 
 int launch_geglu_mlp(const half_t* x, half_t* y, int M, int C, const half_t* img, const float* b1img, const float* gamma,
-                     const float* beta, const float* b2, float eps, hipStream_t stream) {
+                     const float* beta, const float* b2, float eps, hipStream_t stream, float* stats_out) {
     LAVIE_CHECK(geglu_mlp_supported(C), "geglu_mlp: width %d is not built (320 only)", C);
     LAVIE_CHECK(x && y && img && b1img && gamma && beta && b2 && M > 0, "geglu_mlp: bad arguments");
     // algorithmic work: both products; bytes: x in, x' out, the weights once
     ProfileScope prof(KC_FUSED_FF, stream, 2.0 * M * (double)C * 12.0 * C, 2.0 * (2.0 * M * C + 12.0 * C * C), /*kernel_events=*/true);
     GegluMlpParams p;
     p.x = x; p.y = y; p.img = img; p.b1img = b1img; p.gamma = gamma; p.beta = beta; p.b2 = b2;
-    p.M = M; p.tiles = cdiv(M, rf::TOK); p.eps = eps; p.stamps = g_rf_stamps;
+    p.M = M; p.tiles = cdiv(M, rf::TOK); p.eps = eps; p.stamps = g_rf_stamps; p.stats_out = stats_out;
     switch (g_rf_variant) {
         case 1: return launch_geglu_mlp_t<5>(p, stream, prof);
         case 2: return launch_geglu_mlp_t<12>(p, stream, prof);
