@@ -403,10 +403,15 @@ struct AttDmaTile {
 //    16 in-lane values are folded with v_max3 (8 slots), the decision is one compare + ballot over the wave, and the cross-lane
 //    maximum (2 permlane swaps + 2 max) moves into the rare branch that takes it: -8 VALU per tile.
 // Softmax is invariant to the shift, so results differ from V1 only by the rounding of Q' and of exp2's argument.
-template <int NCH, int QT, int NBUF, bool LSUM, bool SC, bool V2 = true>
-__global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void attention_dma_kernel(const AttnParams p) {
+// NW (round 4): waves per workgroup.  Every wave issues its share of a key tile's 2 R LDS-DMA pieces, and an LDS-DMA piece costs its
+// wave 60 - 185 cycles of issue time (MI355X_MICROARCH.md, cycle constants): with 8 waves = 256 queries per workgroup a wave
+// issues half the pieces per tile (and the K / V tiles cross L2 -> LDS half as often); the waves' piece counts may then differ
+// by one (2 R = 12 pieces over 8 waves), so the counted wait takes the wave's own count.
+template <int NCH, int QT, int NBUF, bool LSUM, bool SC, bool V2 = true, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void attention_dma_kernel(const AttnParams p) {
     using T = AttDmaTile<NCH, LSUM>;
-    constexpr int R = T::R, RS = T::RS, PIECES = T::PIECES, NDT = T::NDT;
+    constexpr int R = T::R, RS = T::RS, NDT = T::NDT;
+    constexpr int PIECES = (2 * R + NW - 1) / NW;                      // most pieces one wave issues per tile
     static_assert(R % 4 == 2 && R >= T::NEED && NDT * 32 <= RS, "row stride must be 32 B x odd and hold every output tile's columns");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // buffer b: K at b * 2 * TILE_BYTES, V right behind it
@@ -421,7 +426,8 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
     const int kvb = qb / p.kv_batch_div;
     constexpr int dh = NCH * 8;
     constexpr int nch = NCH;       // 16-byte chunks per key row that exist in HBM
-    const int q0 = blockIdx.x * (4 * QT * 16) + wave * (QT * 16);
+    const int q0 = blockIdx.x * (NW * QT * 16) + wave * (QT * 16);
+    const int my_pieces = (2 * R - wave + NW - 1) / NW;               // pieces x = wave, wave + NW, ... < 2 R (wave-uniform)
 
     // ---- Q fragments (B operand): lane holds Q[q = li][dims 32 ks + 8 g .. +7]
     half8_t qf[QT][T::KS32];
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
     int pkey[PIECES], pch[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-        const int x = wave + 4 * i;
+        const int x = wave + NW * i;
         const int chunk = (x % R) * 64 + lane;
         pkey[i] = chunk / R;
         pch[i] = chunk - pkey[i] * R;
@@ -473,7 +479,8 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
         char* bbase = smem + buf * (2 * T::TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int x = wave + 4 * i;                       // wave-uniform
+            const int x = wave + NW * i;                      // wave-uniform
+            if (2 * R % NW != 0 && x >= 2 * R) break;         // (8 waves: the last round of pieces is only half full)
             const bool is_v = x >= R;
             int key = key0 + pkey[i];
             key = key < p.Lk ? key : p.Lk - 1;                // keys past Lk: any finite row (their scores are masked)
@@ -515,8 +522,9 @@ __global__ __launch_bounds__(256, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) void
     int buf = 0;
     for (int t = 0; t < ntile; ++t) {
         // tile t has landed: all but the pieces of tile t+1 (when it exists) are done; then everybody's pieces
-        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 1 >= ntile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (2 * R % NW == 0 || my_pieces == PIECES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES - 1) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -749,6 +757,16 @@ static int launch_att_dma(const AttnParams& p, hipStream_t stream) {
     // (and the 77-key text cross-attention at head dim 40: two key tiles, the first of which always takes the rescale branch —
     // measured 41 -> 46 us at level 0, tools/ab_attn_v2.py)
     const bool short_keys = NCH == 5 && p.Lk <= 2 * ATT_KEYS;
+    if constexpr (NCH == 5 && QT == 2) {
+        // level-0 self-attention (2560 keys): 8 waves = 256 queries per workgroup (0x70: A/B switch back to 4 waves)
+        if (g_force_qt != 0x60 && g_force_qt != 0x70 && !short_keys && p.Lq % (8 * QT * 16) == 0) {
+            auto kern8 = attention_dma_kernel<NCH, QT, NBUF, LSUM, SC, true, 8>;
+            if (int rc = ensure_dynamic_lds((const void*)kern8, lds)) return rc;
+            hipLaunchKernelGGL(kern8, dim3(p.Lq / (8 * QT * 16), p.heads, p.NBq), dim3(512), lds, stream, p);
+            LAVIE_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     auto kern = (g_force_qt == 0x60 || !V2_OK || short_keys) ? attention_dma_kernel<NCH, QT, NBUF, LSUM, SC, false>
                                                 : attention_dma_kernel<NCH, QT, NBUF, LSUM, SC, V2_OK>;
     if (int rc = ensure_dynamic_lds((const void*)kern, lds)) return rc;

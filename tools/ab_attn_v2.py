@@ -26,20 +26,20 @@ for nb, l, c, lk, div, name in cases:
     ref = ref.transpose(0, 1).reshape(l, c)
     row = f"{name:10s} nb={nb} Lq={l} Lk={lk} dh={dh:3d} | "
     outs = {}
-    for mode in (0x60, 0, 0x60, 0):
+    for mode in (0x60, 0x70, 0, 0x60, 0x70, 0):       # 0x60: round-3 softmax; 0x70: round-4 softmax, 4 waves; 0: + 8 waves at level 0
         lib.lavie_debug_attention_qt(mode)
         outs[mode] = fn().float().clone()
         us = timeit(fn, iters=30)
-        row += f"{'r3' if mode else 'r4'} {us:7.1f} us {4.0 * nb * l * lk * c / us / 1e6:5.0f} TF/s | "
+        row += f"{ {0x60: 'r3', 0x70: 'r4/4w', 0: 'r4'}[mode]} {us:7.1f} us {4.0 * nb * l * lk * c / us / 1e6:5.0f} TF/s | "
     rl = lambda a, b: float((a - b).norm() / b.norm())
     row += f"r4 vs r3 {rl(outs[0], outs[0x60]):.2e}  vs fp32: r3 {rl(outs[0x60][:l], ref):.2e} r4 {rl(outs[0][:l], ref):.2e}"
     print(row, flush=True)
 lib.lavie_debug_attention_qt(0)
 nb, l, c = 61, 2560, 320      # sparse-causal (interpolation model): F = 61 frames at L0
 qkv = rnd(nb * l, 3 * c)
-for mode in (0x60, 0, 0x60, 0):
+for mode in (0x60, 0x70, 0, 0x60, 0x70, 0):
     lib.lavie_debug_attention_qt(mode)
     fn = lambda: ops.sparse_causal_attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], nb=nb, frames=61, d=l, heads=8)
     us = timeit(fn, iters=10)
-    print(f"sparse-causal L0 F=61 {'r3' if mode else 'r4'}: {us:8.1f} us", flush=True)
+    print(f"sparse-causal L0 F=61 { {0x60: 'r3', 0x70: 'r4/4w', 0: 'r4'}[mode]}: {us:8.1f} us", flush=True)
 lib.lavie_debug_attention_qt(0)
