@@ -23,7 +23,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 static unsigned long g_debug_epoch = 0;
-static int g_fused_mask = 0x37;        // bit 0: fused feed-forward, 1: fused temporal sub-block, 2: fused text cross-attention, 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (off), 4: parity form of the upsample convs, 5: GroupNorm statistics from the producers' epilogues (A/B switches); 6: debug verification of those statistics against the statistics pass (off)
+static int g_fused_mask = 0xB7;        // bit 0: fused feed-forward, 1: fused temporal sub-block, 2: fused text cross-attention, 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (off), 4: parity form of the upsample convs, 5: GroupNorm statistics from the producers' epilogues (A/B switches); 6: debug verification of those statistics against the statistics pass (off); 7: LayerNorm row statistics folded in the consuming GEMM's epilogue instead of a finalize launch
 void set_fused_mask(int m) { g_fused_mask = m; }
 int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
@@ -622,13 +622,19 @@ struct FwdCtx {
                 (size_t)(count) * sizeof(type))
 
 struct LnFold {            // consumer side of a folded LayerNorm
-    const float* stats;    // [M, 2] (mean, rstd) of the rows
+    float* stats;          // [M, 2] (mean, rstd) of the rows
     const float* s;        // row sums of the folded weights
+    // round 4: the producer leaves its partials un-finalized; a consumer on a kernel with the shared epilogue folds them itself
+    // (IgemmParams::ln_partials), the persistent kernel's consumers finalize on demand, once
+    const float* partials = nullptr;   // [M, slots, 2] of the rows' latest producer, or nullptr when `stats` was written directly
+    int slots = 0, row_len = 0, rows = 0;
+    bool final_ok = false;             // `stats` holds the finalized (mean, rstd) of the current rows
 };
 struct RowStat {           // producer side: partials [M, slots, 2] -> (mean, rstd) [M, 2]
     float* partials;
     float* mean_rstd;
     int slots;
+    LnFold* sink = nullptr;            // told where the partials are (no finalize launch); nullptr = finalize at once
 };
 
 // GroupNorm statistics from the producing kernel (igemm.h colstat_out, round 4).  Every tensor a GroupNorm may read gets a small
@@ -655,7 +661,7 @@ static void colstat_plan(IgemmParams& p, bool gather, float* buf, GnColStat* out
 }
 
 static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const float* bias, int N, int K, const half_t* R,
-                  half_t* C, int ldc, int M, int epilogue = EPI_LINEAR, const LnFold* fold = nullptr,
+                  half_t* C, int ldc, int M, int epilogue = EPI_LINEAR, LnFold* fold = nullptr,
                   const RowStat* rowstat = nullptr, int ldw = 0, float* cs_buf = nullptr, GnColStat* cs_out = nullptr) {
     const bool unsplit = fold != nullptr || rowstat != nullptr;
     if (cs_out) *cs_out = GnColStat();
@@ -676,7 +682,19 @@ static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const fl
     p.splits = unsplit ? 1 : igemm_plan_splits(M, N, p.nk, epilogue);
     p.rowstat_out = rowstat ? rowstat->partials : nullptr;
     p.rowstat_cols = rowstat ? N / rowstat->slots : 0;
-    if (fold) { p.ln_stats = fold->stats; p.ln_s = fold->s; }
+    if (fold) {
+        p.ln_s = fold->s;
+        const bool ppx = igemm_takes_ppx(M, N, p.nk, epilogue);
+        if (fold->partials && !fold->final_ok && !ppx && fold->rows >= M && (fused_mask() & 128)) {          // fold in this GEMM's epilogue: no finalize launch
+            p.ln_partials = fold->partials; p.ln_slots = fold->slots; p.ln_inv_len = 1.0f / (float)fold->row_len; p.ln_eps = 1e-5f;
+        } else {
+            if (fold->partials && !fold->final_ok) {       // the persistent kernel stages finished rows: finalize now, once
+                RUN(launch_rowstat_finalize(fold->partials, fold->slots, fold->rows, fold->row_len, 1e-5f, fold->stats, c.s));
+                fold->final_ok = true;
+            }
+            p.ln_stats = fold->stats;
+        }
+    }
     if (epilogue == EPI_LINEAR && ldc == N) colstat_plan(p, false, cs_buf, cs_out);
     const size_t mark = c.ws->mark();
     if (p.splits > 1) {
@@ -684,7 +702,14 @@ static int linear(FwdCtx& c, const half_t* A, int lda, const half_t* W, const fl
         LAVIE_CHECK(p.slab != nullptr, "workspace exhausted (split-K slab)");
     }
     int rc = launch_igemm(p, false, epilogue, c.s);
-    if (rc == 0 && rowstat) rc = launch_rowstat_finalize(rowstat->partials, rowstat->slots, M, N, 1e-5f, rowstat->mean_rstd, c.s);
+    if (rc == 0 && rowstat) {
+        if (rowstat->sink) {       // deferred: the consumer decides (see above)
+            rowstat->sink->partials = rowstat->partials; rowstat->sink->slots = rowstat->slots; rowstat->sink->row_len = N;
+            rowstat->sink->rows = M; rowstat->sink->final_ok = false;
+        } else {
+            rc = launch_rowstat_finalize(rowstat->partials, rowstat->slots, M, N, 1e-5f, rowstat->mean_rstd, c.s);
+        }
+    }
     c.ws->release(mark);
     return rc;
 }
@@ -907,7 +932,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     const bool fused_x = t.xb_tmpl != nullptr && kv_cached && xb_bound_ && xb_img_[ti] != nullptr && (ff_first ? fused_ff : fused_t) &&
                          !t.attn1_cross && (fused_mask() & 4) && cross_block_supported(C, heads, c.ctx_len, c.F * D);
     LnFold lf{nullptr, nullptr};
-    RowStat rsd{nullptr, nullptr, C / igemm_rowstat_cols(T, C, C / IGEMM_BK)};
+    RowStat rsd{nullptr, nullptr, C / igemm_rowstat_cols(T, C, C / IGEMM_BK), &lf};
     const RowStat* rowstat = nullptr;
     if (fold) {
         WS(rsp, float, (size_t)T * (C / 32) * 2);
@@ -1025,8 +1050,8 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         if (fused_ff) {        // norm3 -> ff1 -> GEGLU -> ff2 -> + residual in ONE kernel, in place on the residual stream
             // interpolation order: norm_temp consumes this output; the kernel writes its (mean, rstd) rows where ff2's epilogue +
             // rowstat_finalize would have put them
-            LAUNCH(launch_geglu_mlp(tx, tx, T, C, t.ff_img, t.ff_b1img, t.ln3.g, t.ln3.b, t.ff2.b, 1e-5f, c.s,
-                                    ff_first ? const_cast<float*>(lf.stats) : nullptr));
+            LAUNCH(launch_geglu_mlp(tx, tx, T, C, t.ff_img, t.ff_b1img, t.ln3.g, t.ln3.b, t.ff2.b, 1e-5f, c.s, ff_first ? lf.stats : nullptr));
+            if (ff_first) { lf.partials = nullptr; lf.final_ok = true; }       // finished rows, written by the kernel itself
             return 0;
         }
         if (fold && !fused_t) {       // (the fused temporal kernel emits no row statistics: explicit LayerNorm behind it)

@@ -42,6 +42,12 @@ struct IgemmParams {
     int rowstat_cols;          // columns per slot the caller sized rowstat_out for (igemm_rowstat_cols); launch_igemm checks that
                                // the kernel it selects writes slots of exactly this width (0 = unchecked)
     const float* ln_stats;     // [M, 2] (mean, rstd) of the A rows (launch_rowstat_finalize), or nullptr
+    // ... or (round 4) the producer's partials themselves: the epilogue folds the ln_slots pairs of a row with rowstat_finalize's
+    // arithmetic, and the finalize launch disappears.  Kernels with the shared epilogue only (the persistent kernel stages finished
+    // (mean, rstd) rows through LDS and has no room for the partials): launch_igemm refuses the combination.
+    const float* ln_partials;  // [M, ln_slots, 2] (sum, sum of squares) or nullptr (then ln_stats)
+    int ln_slots;
+    float ln_inv_len, ln_eps;  // 1 / row length of the normalised rows, epsilon
     const float* ln_s;         // [N]: s_n = sum_k W'[n, k]
     // GroupNorm statistics from the producer (round 4): per (row block, channel) sum and sum of squares of the ROUNDED fp16 output,
     // written by the epilogue that stores the tensor (or by the split-K reduce), so that the consuming GroupNorm needs no statistics
@@ -96,6 +102,8 @@ int igemm_plan_splits_gather(const IgemmParams& p);
 bool igemm_patch_planned(const IgemmParams& p);
 // wave-tile width (16*NT) launch_igemm will pick for a plain, unsplit EPI_LINEAR GEMM: the row-statistics slot width
 int igemm_rowstat_cols(int M, int N, int nk);
+// whether launch_igemm hands a plain GEMM of this shape (unsplit) to the persistent ping-pong kernel
+bool igemm_takes_ppx(int M, int N, int nk, int epilogue);
 // rows per column-statistics block of the kernel launch_igemm will run for `p` (geometry, segments and p.splits filled in):
 // 80 (halo-patch, ping-pong and persistent kernels), 64 (128-row kernel), 32 (split-K: the reduce kernel writes them),
 // 0 = this launch cannot emit them (2-D patch tiles, GEGLU)

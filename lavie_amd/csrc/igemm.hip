@@ -479,6 +479,7 @@ bool igemm_patch_planned(const IgemmParams& p) {
 }
 
 int igemm_plan_splits(int M, int N, int nk, int epilogue) { return plan_splits(M, N, nk, epilogue, true); }
+bool igemm_takes_ppx(int M, int N, int nk, int epilogue) { return ppx_plan_shape(M, N, nk, epilogue); }
 
 static int plan_splits(int M, int N, int nk, int epilogue, bool plain) {
     if (epilogue != EPI_LINEAR || N % 64 != 0) return 1;
@@ -620,7 +621,8 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     ProfileScope prof(gather ? KC_CONV3X3 : KC_LINEAR, stream, 2.0 * p.M * p.N * K,
                       2.0 * ((double)p.M * K / (gather ? 9.0 : 1.0) + (double)p.N * K + (double)p.M * p.N));
     LAVIE_CHECK(p.N % 4 == 0 && p.ldc % 4 == 0, "igemm: N and ldc must be multiples of 4");
-    LAVIE_CHECK(!(p.rowstat_out || p.ln_stats) || (p.splits == 1 && !gather), "igemm: LayerNorm folding needs a plain, unsplit GEMM");
+    LAVIE_CHECK(!(p.rowstat_out || p.ln_stats || p.ln_partials) || (p.splits == 1 && !gather), "igemm: LayerNorm folding needs a plain, unsplit GEMM");
+    LAVIE_CHECK(!p.ln_partials || (p.ln_slots >= 1 && !ppx_plan(p, epilogue)), "igemm: row-statistics partials cannot feed the persistent kernel (finalize them)");
     LAVIE_CHECK(p.splits >= 1 && p.splits <= p.nk && (p.splits == 1 || (p.slab && epilogue == EPI_LINEAR)),
                 "igemm: bad split-K setup (splits=%d)", p.splits);
     const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);      // 8 = automatic without the persistent kernel

@@ -55,7 +55,7 @@ template <int MT, int NT, int EPI, class RowFn>
 __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 (&acc)[NT][MT], RowFn rowof, int ncol, int nwave0,
                                                     int lane, int split, int cs_block = -1) {
     // ---- folded LayerNorm of the A rows: acc <- rstd_m * (acc - mean_m * s_n); the folded bias comes in as p.bias
-    if (p.ln_stats) {
+    if (p.ln_stats || p.ln_partials) {
         f32x4 sv[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) sv[nt] = *reinterpret_cast<const f32x4*>(p.ln_s + ncol + nt * 16);
@@ -64,8 +64,16 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 
         for (int mt = 0; mt < MT; ++mt) {
             const int m = rowof(mt);
             const int mc = m < p.M ? m : p.M - 1;
-            mean[mt] = p.ln_stats[(size_t)mc * 2];
-            rstd[mt] = p.ln_stats[(size_t)mc * 2 + 1];
+            if (p.ln_partials) {        // fold the producer's per-wave-tile partials here (rowstat_finalize_kernel's arithmetic and order)
+                const float2* st = reinterpret_cast<const float2*>(p.ln_partials) + (size_t)mc * p.ln_slots;
+                float sum = 0.f, sq = 0.f;
+                for (int j = 0; j < p.ln_slots; ++j) { const float2 v = st[j]; sum += v.x; sq += v.y; }
+                mean[mt] = sum * p.ln_inv_len;
+                rstd[mt] = rsqrtf(fmaxf(sq * p.ln_inv_len - mean[mt] * mean[mt], 0.f) + p.ln_eps);
+            } else {
+                mean[mt] = p.ln_stats[(size_t)mc * 2];
+                rstd[mt] = p.ln_stats[(size_t)mc * 2 + 1];
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
