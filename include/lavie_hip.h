@@ -210,7 +210,8 @@ int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long lo
  * default), 4 = parity form of the Upsample3D convs (lavie_upsample_conv3x3_f16), 5 = GroupNorm statistics taken from the
  * producing kernel's epilogue instead of a statistics pass (round 4).  Bit 6 (debug, off): every GroupNorm that takes producer statistics ALSO runs
  * the statistics pass and compares the two on the host.  Bit 7: a LayerNorm-folded GEMM on a kernel with the shared epilogue folds its producer's row-statistics partials itself (no
- * rowstat_finalize launch; the persistent kernel's consumers still finalize, once).  Default 0xB7 (bits 0, 1, 2, 4, 5, 7); 0 = the one-GEMM-per-launch path of round 2. */
+ * rowstat_finalize launch; the persistent kernel's consumers still finalize, once) — measured SLOWER (every N tile of the consumer
+ * repeats the fold: linear class 7.23 -> 7.89 ms per forward, profiles/r04_ab_rowstat_fold_in_consumer.txt): off.  Default 0x37 (bits 0, 1, 2, 4, 5); 0 = the one-GEMM-per-launch path of round 2. */
 int lavie_debug_fused_mask(int mask);
 /* Test hook: GroupNorm launches so far (process-wide) that took their statistics from the producers' epilogues.  Bit 6 of the mask
  * above makes every such launch ALSO run the statistics pass and compare the two on the host (synchronises; an error names the

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
 ABI_VERSION = 6
-FUSED_DEFAULT = 0xB7     # lavie_debug_fused_mask: bits 0, 1, 2, 4, 5, 7 (include/lavie_hip.h)
+FUSED_DEFAULT = 0x37     # lavie_debug_fused_mask: bits 0, 1, 2, 4, 5 (include/lavie_hip.h)
 MAX_LEVELS = 8
 
 c_void_p, c_int, c_float, c_ll, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_char_p
