@@ -457,7 +457,7 @@ static bool patch_fits(int M, int N, int nk, int s, int ntaps = 9) {
     return r / ceil(r) >= 0.85;
 }
 static int pt_bm_rows() { return 320; }      // the halo-patch kernel's tile height (igemm_patch.hip pt::BM)
-static bool patch_allowed() { const int lo = g_force_tile & 0xF; return lo == 0 || lo == 5 || lo == 8; }
+static bool patch_allowed() { const int lo = g_force_tile & 0xF; return lo == 0 || lo == 5 || lo == 8 || lo == 9; }
 
 static int plan_splits(int M, int N, int nk, int epilogue, bool plain);
 static bool ppx_plan_shape(int M, int N, int nk, int epilogue);
@@ -474,7 +474,7 @@ int igemm_plan_splits_gather(const IgemmParams& p) {
 }
 
 bool igemm_patch_planned(const IgemmParams& p) {
-    const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);
+    const int lo = ((g_force_tile & 0xF) == 8 || (g_force_tile & 0xF) == 9) ? 0 : (g_force_tile & 0xF);
     return igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)));
 }
 
@@ -505,6 +505,10 @@ static bool ppx_plan_shape(int M, int N, int nk, int epilogue) {
     const int lo = g_force_tile & 0xF;
     if (M % 160 != 0 || nk < 5 || (epilogue == EPI_GEGLU ? N % 256 != 0 : (N % 320 != 0 && N % 256 != 0))) return false;   // = igemm_ppx_eligible's shape part
     if (lo == 7) return true;
+    if (lo == 9) {      // experiment switch (round 4): the automatic rule, plus GEGLU GEMMs with short K loops on the persistent kernel
+        const long tiles9 = (long)(M / 160) * (N / pp_bn(N));
+        return tiles9 >= 256 && nk <= 10;
+    }
     if (lo != 0 && lo != 6) return false;
     // Measured (tools/check_ppx.py, profiles/r02_ppx_shapes.txt): the persistent kernel wins where the K loop is short and
     // every CU gets at least one whole tile — the L0 GEMMs with K = 320 (N = 320: -14 .. -23 %, QKV -7 %, GEGLU -10 %) and
@@ -586,7 +590,7 @@ int igemm_rowstat_cols(int M, int N, int nk) {
 int igemm_colstat_rows(const IgemmParams& p, bool gather, int epilogue) {
     if (epilogue != EPI_LINEAR || p.N % 4 != 0) return 0;
     if (p.splits > 1) return COLSTAT_REDUCE_ROWS;                 // whatever kernel fills the slabs, the reduce kernel writes the statistics
-    const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);
+    const int lo = ((g_force_tile & 0xF) == 8 || (g_force_tile & 0xF) == 9) ? 0 : (g_force_tile & 0xF);
     if (p.par_ups) return 80;                                     // source-row blocks, one set per parity
     if (!gather && ppx_plan(p, epilogue)) return 80;
     if (gather && igemm_patch_eligible(p) && (lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)))) {
@@ -600,7 +604,7 @@ int igemm_colstat_rows(const IgemmParams& p, bool gather, int epilogue) {
 
 int igemm_colstat_span(const IgemmParams& p, bool gather, int rows) {
     if (p.splits > 1) return rows;                                 // the reduce kernel walks contiguous output rows
-    const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);
+    const int lo = ((g_force_tile & 0xF) == 8 || (g_force_tile & 0xF) == 9) ? 0 : (g_force_tile & 0xF);
     const bool patch = gather && igemm_patch_eligible(p) &&
                        (p.par_ups || lo == 5 || (lo == 0 && patch_fits(p.M, p.N, p.nk, p.splits, p.tframes > 0 ? p.seg[0].ntaps : 9)));
     if (!patch) return rows;
@@ -625,7 +629,7 @@ int launch_igemm(const IgemmParams& p, bool gather, int epilogue, hipStream_t st
     LAVIE_CHECK(!p.ln_partials || (p.ln_slots >= 1 && !ppx_plan(p, epilogue)), "igemm: row-statistics partials cannot feed the persistent kernel (finalize them)");
     LAVIE_CHECK(p.splits >= 1 && p.splits <= p.nk && (p.splits == 1 || (p.slab && epilogue == EPI_LINEAR)),
                 "igemm: bad split-K setup (splits=%d)", p.splits);
-    const int lo = (g_force_tile & 0xF) == 8 ? 0 : (g_force_tile & 0xF);      // 8 = automatic without the persistent kernel
+    const int lo = ((g_force_tile & 0xF) == 8 || (g_force_tile & 0xF) == 9) ? 0 : (g_force_tile & 0xF);      // 8 = automatic without the persistent kernel
     auto reduce_splits = [&]() -> int {          // fixed-order sum of the split-K slabs + bias / residual / rounding
         return p.splits > 1 ? launch_splitk_reduce(p, stream) : 0;
     };
