@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAVIE_ABI_VERSION 6
+#define LAVIE_ABI_VERSION 7
 #define LAVIE_MAX_LEVELS 8
 
 const char* lavie_last_error(void);

@@ -7,7 +7,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 FUSED_DEFAULT = 0x37     # lavie_debug_fused_mask: bits 0, 1, 2, 4, 5 (include/lavie_hip.h)
 MAX_LEVELS = 8
 

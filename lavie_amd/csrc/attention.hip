@@ -580,12 +580,13 @@ __global__ __launch_bounds__(64 * NW, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) 
         }
 
         half8_t pb[2][QT];
-        // ---- online softmax per query column, deferred rescale (as the register-staged kernel)
+        if constexpr (V2) {
+            // s = (scores - m_run) in log2 units.  In-lane maximum of the lane's 16 keys per query tile (8 v_max3 each); whether ANY
+            // row of the wave outgrew the threshold is one compare + ballot for both query tiles; the first tile always takes
+            // the branch (m_run = -inf there)
+            float mxl[QT];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            if constexpr (V2) {
-                // s = (scores - m_run) in log2 units.  In-lane maximum of the lane's 16 keys (8 v_max3); whether ANY row of the wave
-                // outgrew the threshold is one compare + ballot; the first tile always takes the branch (m_run = -inf there)
+            for (int qt = 0; qt < QT; ++qt) {
                 float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), s[0][qt][2]);
                 mx = fmaxf(fmaxf(mx, s[0][qt][3]), s[1][qt][0]);
                 mx = fmaxf(fmaxf(mx, s[1][qt][1]), s[1][qt][2]);
@@ -593,10 +594,17 @@ __global__ __launch_bounds__(64 * NW, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) 
                 mx = fmaxf(fmaxf(mx, s[2][qt][1]), s[2][qt][2]);
                 mx = fmaxf(fmaxf(mx, s[2][qt][3]), s[3][qt][0]);
                 mx = fmaxf(fmaxf(mx, s[3][qt][1]), s[3][qt][2]);
-                mx = fmaxf(mx, s[3][qt][3]);
-                if (t == 0 || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {
-                    // rare: fold the four lane groups (the query's 64 keys), move the running maximum of the rows that grew,
-                    // rescale O (and l), shift this tile's scores and the accumulator initialiser
+                mxl[qt] = fmaxf(mx, s[3][qt][3]);
+            }
+            float mxa = mxl[0];
+#pragma unroll
+            for (int qt = 1; qt < QT; ++qt) mxa = fmaxf(mxa, mxl[qt]);
+            if (t == 0 || __builtin_amdgcn_ballot_w64(mxa > RESCALE_THR) != 0) {
+                // rare: fold the four lane groups (the query's 64 keys), move the running maximum of the rows that grew, rescale
+                // O (and l), shift this tile's scores and the accumulator initialiser
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    float mx = mxl[qt];
                     const unsigned u = __float_as_uint(mx);
                     const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
                     mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
@@ -618,6 +626,9 @@ __global__ __launch_bounds__(64 * NW, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) 
                         for (int r = 0; r < 4; ++r) s[kt][qt][r] -= delta;
                     negm[qt] = (f32x4){nmr, nmr, nmr, nmr};
                 }
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
                 float psum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
@@ -636,8 +647,13 @@ __global__ __launch_bounds__(64 * NW, (NCH == 5 && QT == 2) ? ATT_DMA_OCC5 : 1) 
                     pb[kt >> 1][qt][(kt & 1) * 4 + 3] = h1[1];
                 }
                 if constexpr (!LSUM) l_run[qt] += psum;
-                continue;
             }
+        }
+        // ---- online softmax per query column, deferred rescale (as the register-staged kernel)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            if constexpr (V2) break;        // handled below, both query tiles under ONE decision
+
             // a chain of three-input maxima (v_max3_f32: 8 slots for the 16 scores; the pairwise tree took 13)
             float mx = fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), s[0][qt][2]);
             mx = fmaxf(fmaxf(mx, s[0][qt][3]), s[1][qt][0]);

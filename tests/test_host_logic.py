@@ -91,7 +91,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.lavie_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.lavie_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_relpos_buckets_host_function():
