@@ -516,9 +516,12 @@ static bool ppx_plan_shape(int M, int N, int nk, int epilogue) {
     // hides their epilogue better) and on under-filled grids (M = 5120: 128 tiles).
     // GEGLU: -10 % in the operator benchmark but +3 % inside the UNet (rocprofv3, profiles/r02_a_kernel_summary.md: its
     // VALU-heavy epilogue stalls both groups once per tile): left to the one-tile kernels.
+    // Round 4, re-measured inside the forward (tools/ab_tile.py, profiles/r04_ab_geglu_on_persistent_kernel.txt, same box,
+    // interleaved): with the level-1 GEGLU GEMM (K = 640) on the persistent kernel the forward is 0.1 - 0.2 ms shorter in four
+    // rounds of four (linear class 7.38 -> 7.26 ms): taken (mode 6 keeps the round-3 rule for A/B).
     const long tiles = (long)(M / 160) * (N / pp_bn(N));
     if (tiles < 256 || nk > 10) return false;
-    return epilogue == EPI_LINEAR;
+    return epilogue == EPI_LINEAR || lo == 0;
 }
 static bool ppx_plan(const IgemmParams& p, int epilogue) {
     return p.splits == 1 && igemm_ppx_eligible(p, epilogue) && ppx_plan_shape(p.M, p.N, p.nk, epilogue);
