@@ -146,6 +146,22 @@ long long lavie_group_norm_ws_floats(int NB, int groups);
 int lavie_group_norm_f16(const void* x1, int C1, const void* x2, int C2, int NB, int P, int groups, const float* gamma,
                          const float* beta, float eps, int silu, float* stats_ws, void* y, void* stream);
 
+/* Fused head of the transformer block (ABI 7, round 4): with GN = the per-frame GroupNorm of Transformer3DModel (attention.py:369),
+ *     tx  = proj_in(GN(x))                               (attention.py:371-373: 1x1 conv, then tokens)
+ *     qkv = [to_q | to_k | to_v](norm1(tx))              (attention.py:513-516 with CrossAttention :154, 177-178)
+ * as ONE kernel: the normalised copy of x, norm1's statistics and the re-read of tx never exist in memory.  The GroupNorm is handed
+ * over as per-(frame, channel) pairs (a, b), y = a x + b: lavie_group_norm_affine_f16 computes the statistics (as
+ * lavie_group_norm_f16 does) and writes ab_out [NB][C][2] instead of a normalised tensor.  rows_per_domain = rows per frame (a
+ * multiple of 16 that divides M).  Built for C = 320: lavie_proj_qkv_image_bytes returns 0 otherwise.
+ *   wpin [C, C] = proj_in.weight (1x1 conv or Linear), wqkv [3C, C] = attn1.to_q / to_k / to_v rows stacked (fp16, device);
+ *   bpin: proj_in.bias fp32 [C]; ln_gamma / ln_beta: norm1 fp32 [C]; tx [M, C], qkv [M, 3C] fp16 out. */
+long long lavie_proj_qkv_image_bytes(int C);
+int lavie_pack_proj_qkv_f16(const void* wpin, const void* wqkv, int C, void* img, void* stream);
+int lavie_group_norm_affine_f16(const void* x, int C, int NB, int P, int groups, const float* gamma, const float* beta, float eps,
+                                float* stats_ws, float* ab_out, void* stream);
+int lavie_proj_qkv_f16(const void* x, const float* gn_ab, int rows_per_domain, const void* img, const float* bpin, const float* ln_gamma,
+                       const float* ln_beta, float ln_eps, void* tx, void* qkv, int M, int C, void* stream);
+
 /* nn.LayerNorm(C) over rows (attention.py:442,459,474,480). */
 int lavie_layer_norm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                          void* stream);
@@ -211,7 +227,8 @@ int lavie_latents_to_scaled_model_input1(const float* x, void* model_in, long lo
  * producing kernel's epilogue instead of a statistics pass (round 4).  Bit 6 (debug, off): every GroupNorm that takes producer statistics ALSO runs
  * the statistics pass and compares the two on the host.  Bit 7: a LayerNorm-folded GEMM on a kernel with the shared epilogue folds its producer's row-statistics partials itself (no
  * rowstat_finalize launch; the persistent kernel's consumers still finalize, once) — measured SLOWER (every N tile of the consumer
- * repeats the fold: linear class 7.23 -> 7.89 ms per forward, profiles/r04_ab_rowstat_fold_in_consumer.txt): off.  Default 0x37 (bits 0, 1, 2, 4, 5); 0 = the one-GEMM-per-launch path of round 2. */
+ * repeats the fold: linear class 7.23 -> 7.89 ms per forward, profiles/r04_ab_rowstat_fold_in_consumer.txt): off.  Bit 8: the fused block head
+ * (lavie_proj_qkv_f16: GroupNorm -> proj_in -> norm1 -> q|k|v in one kernel).  Default 0x137 (bits 0, 1, 2, 4, 5, 8); 0 = the one-GEMM-per-launch path of round 2. */
 int lavie_debug_fused_mask(int mask);
 /* Test hook: GroupNorm launches so far (process-wide) that took their statistics from the producers' epilogues.  Bit 6 of the mask
  * above makes every such launch ALSO run the statistics pass and compare the two on the host (synchronises; an error names the

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAVIE_HIP_LIB") or os.path.join(_HERE, "liblavie_hip.so")   # env override: A/B builds
 ABI_VERSION = 7
-FUSED_DEFAULT = 0x37     # lavie_debug_fused_mask: bits 0, 1, 2, 4, 5 (include/lavie_hip.h)
+FUSED_DEFAULT = 0x137    # lavie_debug_fused_mask: bits 0, 1, 2, 4, 5, 8 (include/lavie_hip.h)
 MAX_LEVELS = 8
 
 c_void_p, c_int, c_float, c_ll, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_char_p
@@ -59,6 +59,11 @@ SIGNATURES = {
     "lavie_pack_conv3x3_parity_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lavie_upsample_conv3x3_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "lavie_upsample_conv3x3_f16": (c_int, [c_void_p, c_void_p, c_float_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lavie_proj_qkv_image_bytes": (c_ll, [c_int]),
+    "lavie_pack_proj_qkv_f16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "lavie_group_norm_affine_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float_p, c_float_p, c_float, c_float_p, c_float_p, c_void_p]),
+    "lavie_proj_qkv_f16": (c_int, [c_void_p, c_float_p, c_int, c_void_p, c_float_p, c_float_p, c_float_p, c_float, c_void_p, c_void_p,
+                                    c_int, c_int, c_void_p]),
     "lavie_group_norm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float_p, c_float_p, c_float,
                                       c_int, c_float_p, c_void_p, c_void_p]),
     "lavie_group_norm_ws_floats": (c_ll, [c_int, c_int]),

@@ -206,6 +206,22 @@ int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float
     return rc;
 }
 
+long long lavie_proj_qkv_image_bytes(int C) { return proj_qkv_supported(C) ? (long long)proj_qkv_image_bytes(C) : 0; }
+int lavie_pack_proj_qkv_f16(const void* wpin, const void* wqkv, int C, void* img, void* stream) {
+    LAVIE_CHECK(wpin && wqkv && img, "pack_proj_qkv: null tensor");
+    return pack_proj_qkv(H(wpin), H(wqkv), C, (half_t*)img, S(stream));
+}
+int lavie_group_norm_affine_f16(const void* x, int C, int NB, int P, int groups, const float* gamma, const float* beta, float eps,
+                                float* stats_ws, float* ab_out, void* stream) {
+    LAVIE_CHECK(x && gamma && beta && stats_ws && ab_out, "group_norm_affine: null tensor");
+    LAVIE_CHECK(NB > 0 && P > 0 && groups > 0, "group_norm_affine: empty problem");
+    return launch_group_norm(H(x), C, nullptr, 0, NB, P, groups, gamma, beta, eps, false, stats_ws, nullptr, S(stream), nullptr, nullptr, ab_out);
+}
+int lavie_proj_qkv_f16(const void* x, const float* gn_ab, int rows_per_domain, const void* img, const float* bpin, const float* ln_gamma,
+                       const float* ln_beta, float ln_eps, void* tx, void* qkv, int M, int C, void* stream) {
+    return launch_proj_qkv(H(x), gn_ab, rows_per_domain, H(img), bpin, ln_gamma, ln_beta, ln_eps, (half_t*)tx, (half_t*)qkv, M, C, S(stream));
+}
+
 int lavie_group_norm_f16(const void* x1, int C1, const void* x2, int C2, int NB, int P, int groups, const float* gamma,
                          const float* beta, float eps, int silu, float* stats_ws, void* y, void* stream) {
     LAVIE_CHECK(x1 && gamma && beta && stats_ws && y, "group_norm: null tensor");

@@ -23,7 +23,7 @@ void set_error(const char* fmt, ...) {
 const char* get_error() { return g_err; }
 
 static unsigned long g_debug_epoch = 0;
-static int g_fused_mask = 0x37;        // bit 0: fused feed-forward, 1: fused temporal sub-block, 2: fused text cross-attention, 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (off), 4: parity form of the upsample convs, 5: GroupNorm statistics from the producers' epilogues (A/B switches); 6: debug verification of those statistics against the statistics pass (off); 7: LayerNorm row statistics folded in the consuming GEMM's epilogue instead of a finalize launch (measured slower: off)
+static int g_fused_mask = 0x137;        // bit 0: fused feed-forward, 1: fused temporal sub-block, 2: fused text cross-attention, 3: conv_shortcut as its own GEMM in front of a halo-patch conv2 (off), 4: parity form of the upsample convs, 5: GroupNorm statistics from the producers' epilogues (A/B switches); 6: debug verification of those statistics against the statistics pass (off); 7: LayerNorm row statistics folded in the consuming GEMM's epilogue instead of a finalize launch (measured slower: off); 8: GroupNorm -> proj_in -> norm1 -> q|k|v as one row-resident kernel
 void set_fused_mask(int m) { g_fused_mask = m; }
 int fused_mask() { return g_fused_mask; }
 void bump_debug_epoch() { ++g_debug_epoch; }
@@ -421,6 +421,12 @@ int UNet::pack_transformer(TransformerW* t, hipStream_t s) {
         NEED(wo1, b + ".attn1.to_out.0.weight"); NEED(wq2, b + ".attn2.to_q.weight"); NEED(wo2, b + ".attn2.to_out.0.weight");
         WALLOC(t->xb_tmpl, half_t, cross_block_image_bytes(C) / sizeof(half_t));
         RUN(pack_cross_block(wo1, wq2, wo2, C, t->xb_tmpl, s));
+    }
+    if (!t->attn1_cross && !cfg_.vsr_blocks && proj_qkv_supported(C)) {     // fused GroupNorm -> proj_in -> norm1 -> q|k|v kernel
+        const half_t* wpin = given(p + ".proj_in.weight");
+        NEED(wpin, p + ".proj_in.weight");
+        WALLOC(t->pq_img, half_t, proj_qkv_image_bytes(C) / sizeof(half_t));
+        RUN(pack_proj_qkv(wpin, t->wqkv1, C, t->pq_img, s));        // wqkv1: to_q | to_k | to_v rows, fused above
     }
     if (geglu_mlp_supported(C)) {      // fused norm3 -> feed-forward -> residual kernel: weight image in MFMA-fragment order
         const half_t* w1 = given(b + ".ff.net.0.proj.weight");
@@ -911,8 +917,17 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     // Tp rows) and `tx` / `att` are copied to the second
     const int NIp = shared_prefix ? NI / 2 : NI, Tp = shared_prefix ? T / 2 : T;
     LAVIE_CHECK(!shared_prefix || (!t.tres.present && !t.attn1_cross && c.B % 2 == 0), "transformer: shared prefix on an unsupported block");
+    // Round 4: GroupNorm -> proj_in -> norm1 -> q|k|v as ONE row-resident kernel (rowfuse_pin.hip; bit 8 of the mask): the norm's
+    // statistics become per-(frame, channel) scale / shift pairs and nothing between x and (tx, qkv) touches memory
+    const bool fused_pq = t.pq_img != nullptr && !t.tres.present && !t.attn1_cross && (fused_mask() & 256) && D % 16 == 0;
+    WS(gn_ab, float, (size_t)NI * C * 2);        // (planned whether or not the switch is on: the plan must not depend on it)
+    if (fused_pq) {
+        LAUNCH(launch_group_norm(x, C, nullptr, 0, NIp, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, nullptr, c.s, x_cs, nullptr, gn_ab));
+        LAUNCH(launch_proj_qkv(x, gn_ab, D, t.pq_img, t.pin.b, t.ln1.g, t.ln1.b, 1e-5f, tx, wide, Tp, C, c.s));
+    } else {
     // per-frame GroupNorm (eps 1e-6) + 1x1 proj_in (attention.py:369-373)
     LAUNCH(launch_group_norm(x, C, nullptr, 0, NIp, D, G, t.gn.g, t.gn.b, 1e-6f, false, c.gn_ws, ln, c.s, x_cs));
+    }
     // LayerNorm folding: the GEMM that produces the residual stream `tx` also emits per-row (sum, sum^2) partials of
     // its fp16 output, and the projection that consumes LN(tx) runs on raw `tx` with gamma folded into its weights,
     // finishing rstd * (acc - mean * s) + b' in its epilogue — no LayerNorm kernel, no normalised copy in HBM.
@@ -944,7 +959,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     }
     RowStat rsd_pin = rsd;                 // the producer's slot width follows the kernel the planner picks for ITS row count
     rsd_pin.slots = C / igemm_rowstat_cols(Tp, C, C / IGEMM_BK);
-    RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, Tp, EPI_LINEAR, nullptr, rowstat ? &rsd_pin : nullptr));
+    if (!fused_pq) RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, Tp, EPI_LINEAR, nullptr, rowstat ? &rsd_pin : nullptr));
 
     if (t.attn1_cross) {
         // VSR only_cross_attention levels: attn1 attends to the text context (vsr/models/attention.py:558-561)
@@ -966,7 +981,9 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         }
     } else {
         // spatial self-attention (attention.py:513-522)
-        if (fold) {
+        if (fused_pq) {
+            // q | k | v already in `wide`
+        } else if (fold) {
             lf.s = t.s_qkv1;
             RUN(linear(c, tx, C, t.f_qkv1, t.b_qkv1, 3 * C, C, nullptr, wide, 3 * C, Tp, EPI_LINEAR, &lf));
         } else {

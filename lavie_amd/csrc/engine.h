@@ -85,6 +85,7 @@ struct TransformerW {
     half_t* ff_img = nullptr; float* ff_b1img = nullptr;    // norm3 -> GEGLU feed-forward -> + residual in one kernel
     half_t* tb_img = nullptr;                               // norm_temp -> q|k|v -> temporal attention -> to_out -> + residual
     half_t* xb_tmpl = nullptr;                              // attn1.to_out -> norm2 -> attn2 -> + residual: weight part of the image (rowfuse_cross.hip)
+    half_t* pq_img = nullptr;                               // GroupNorm -> proj_in -> norm1 -> q|k|v (rowfuse_pin.hip, round 4)
 };
 
 struct SamplerW { half_t* w = nullptr; float* b = nullptr; int C = 0;

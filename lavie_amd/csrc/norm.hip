@@ -300,9 +300,21 @@ static int gn_slabs(int P, int NB, int ty, int cap_total, int* rows_per_slab) {
 size_t gn_workspace_floats(int NB, int groups) { return ((size_t)GN_MAX_SLABS + NB) * groups * 2 + (size_t)NB * groups * 2; }
 
 // stats_ws layout: [NB*groups*2 (mean, rstd)] [partials: NB*slabs*groups*2]
+// (mean, rstd) per (batch, group) -> the normalisation as per-channel pairs: y = a x + b with a = rstd gamma, b = beta - mean a
+__global__ void gn_affine_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 int C, int cpg, int groups, int total, float* __restrict__ ab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // nb * C + c
+    if (i >= total) return;
+    const int nb = i / C, c = i - nb * C;
+    const float* st = stats + ((size_t)nb * groups + c / cpg) * 2;
+    const float a = st[1] * gamma[c];
+    ab[(size_t)i * 2] = a;
+    ab[(size_t)i * 2 + 1] = beta[c] - st[0] * a;
+}
+
 int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* gamma,
                       const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream, const GnColStat* cs1,
-                      const GnColStat* cs2) {
+                      const GnColStat* cs2, float* ab_out) {
     GnGeom g;
     const int ctot = C1 + C2;
     LAVIE_CHECK(gn_geometry(ctot, &g), "group_norm: unsupported channel count %d", ctot);
@@ -361,6 +373,12 @@ int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB
                         "group_norm: producer statistics differ from the statistics pass at (batch, group) %zu of %d x %d (C %d+%d, P %d): mean %g vs %g, "
                         "rstd %g vs %g", i / 2, NB, groups, C1, C2, P, a[i], b[i], a[i + 1], b[i + 1]);
         }
+    }
+    if (ab_out) {        // statistics only: the consumer (rowfuse_pin.hip) applies the norm in registers
+        const int total = NB * ctot;
+        hipLaunchKernelGGL(gn_affine_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, stats, gamma, beta, ctot, ctot / groups, groups, total, ab_out);
+        LAVIE_HIP(hipGetLastError());
+        return 0;
     }
     int rps2;
     const int slabs2 = gn_slabs(P, NB, g.ty, 2048, &rps2);

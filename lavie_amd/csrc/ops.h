@@ -28,7 +28,9 @@ struct GnColStat {
 // fold of the partials; otherwise the two-pass path runs.
 int launch_group_norm(const half_t* x1, int C1, const half_t* x2, int C2, int NB, int P, int groups, const float* gamma,
                       const float* beta, float eps, bool silu, float* ws, half_t* y, hipStream_t stream,
-                      const GnColStat* cs1 = nullptr, const GnColStat* cs2 = nullptr);
+                      const GnColStat* cs1 = nullptr, const GnColStat* cs2 = nullptr, float* ab_out = nullptr);
+// ab_out (optional, [NB][C1 + C2][2] floats): statistics only — instead of the apply pass (y is not written) the normalisation is
+// handed on as per-(batch, channel) pairs (a, b), y = a x + b, for a consumer that applies it in registers (launch_proj_qkv)
 long gn_producer_count();     // GroupNorm launches so far whose statistics came from the producers' epilogues (test hook)
 int launch_layernorm(const half_t* x, const float* gamma, const float* beta, half_t* y, int rows, int C, float eps,
                      hipStream_t stream);
@@ -125,6 +127,14 @@ int pack_temporal_block(const half_t* wq, const half_t* wk, const half_t* wv, co
 int launch_temporal_block(const half_t* x, half_t* y, int B, int F, int D, int C, int heads, const half_t* img,
                           const float* gamma, const float* beta, const float* bo, const float* relbias, const float* rot_cos,
                           const float* rot_sin, int rot_dim, float scale, float eps, hipStream_t stream);
+
+// ---- rowfuse_pin.hip: tx = proj_in(GroupNorm(x)), qkv = [to_q | to_k | to_v](LayerNorm(tx)) in one kernel (C = 320); GroupNorm comes in
+// as the (a, b) pairs of launch_group_norm(..., ab_out), one set per `rows_per_domain` rows (a frame)
+bool proj_qkv_supported(int C);
+size_t proj_qkv_image_bytes(int C);
+int pack_proj_qkv(const half_t* wpin, const half_t* wqkv, int C, half_t* img, hipStream_t stream);
+int launch_proj_qkv(const half_t* x, const float* gn_ab, int rows_per_domain, const half_t* img, const float* bpin, const float* ln_g,
+                    const float* ln_b, float eps, half_t* tx, half_t* qkv, int M, int C, hipStream_t stream);
 
 // ---- rowfuse_cross.hip: x'' = x' + to_out2(attn2(LN2(x'), K, V)), x' = x + to_out1(att), K / V of the text context streamed
 // with the weights (one image per video: pack once per model, bind once per context); y may alias x

@@ -262,6 +262,45 @@ def group_norm(x1, gamma, beta, nb, groups, eps, silu, x2=None):
     return y
 
 
+def group_norm_affine(x, gamma, beta, nb, groups, eps):
+    """GroupNorm statistics only: the normalisation as per-(batch, channel) pairs (a, b) with norm(x) = a x + b -> [nb, C, 2] fp32
+    (lavie_group_norm_affine_f16; consumed by proj_qkv)."""
+    _chk16(x)
+    _chk32(gamma, beta)
+    rows, c = x.shape
+    ab = torch.empty(nb, c, 2, dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.load().lavie_group_norm_ws_floats(nb, groups), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().lavie_group_norm_affine_f16(_p(x), c, nb, rows // nb, groups, _p(gamma), _p(beta), float(eps), _p(ws),
+                                                       _p(ab), _stream()), "lavie_group_norm_affine_f16")
+    return ab
+
+
+def pack_proj_qkv(wpin, wqkv):
+    """proj_in.weight [C, C] and the stacked attn1 to_q / to_k / to_v weights [3C, C] (fp16, device) -> the weight image of the fused
+    block-head kernel (lavie_proj_qkv_f16).  Raises for a width the kernel is not built for."""
+    _chk16(wpin, wqkv)
+    C = wpin.shape[0]
+    lib = _lib.load()
+    nbytes = lib.lavie_proj_qkv_image_bytes(C)
+    if nbytes == 0 or tuple(wpin.shape) != (C, C) or tuple(wqkv.shape) != (3 * C, C):
+        raise RuntimeError(f"proj_qkv: width {C} is not built (or weight shapes do not match)")
+    img = torch.empty(nbytes // 2, dtype=torch.float16, device=wpin.device)
+    _lib.check(lib.lavie_pack_proj_qkv_f16(_p(wpin), _p(wqkv), C, _p(img), _stream()), "lavie_pack_proj_qkv_f16")
+    return img
+
+
+def proj_qkv(x, gn_ab, rows_per_domain, img, bpin, ln_gamma, ln_beta, eps=1e-5):
+    """tx = proj_in(GroupNorm(x)), qkv = to_qkv(LayerNorm(tx)) in one kernel (attention.py:369-373, 513-516) -> (tx [M, C], qkv [M, 3C])."""
+    _chk16(x, img)
+    _chk32(gn_ab, bpin, ln_gamma, ln_beta)
+    M, C = x.shape
+    tx = torch.empty(M, C, dtype=torch.float16, device=x.device)
+    qkv = torch.empty(M, 3 * C, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().lavie_proj_qkv_f16(_p(x), _p(gn_ab), rows_per_domain, _p(img), _p(bpin), _p(ln_gamma), _p(ln_beta), eps,
+                                              _p(tx), _p(qkv), M, C, _stream()), "lavie_proj_qkv_f16")
+    return tx, qkv
+
+
 def layer_norm(x, gamma, beta, eps=1e-5):
     _chk16(x)
     _chk32(gamma, beta)

@@ -140,3 +140,46 @@ def test_cross_block_rejects_long_context():
     tmpl = ops.pack_cross_block(z, z, z)
     with pytest.raises(RuntimeError):
         ops.bind_cross_block(tmpl, torch.zeros(81, 640, dtype=torch.float16, device="cuda"), 1, 81)
+
+
+# 2560 rows per frame = the bench's level-0 frames (passes of 128 rows never straddle a frame); 256: sixteen tiles per frame;
+# 48: three tiles per frame, so the waves of one pass work under different frames' scale / shift pairs, and a ragged last pass
+@pytest.mark.parametrize("NB,D", [(4, 2560), (6, 256), (5, 48)])
+def test_proj_qkv_fused(NB, D):
+    """Transformer3DModel's per-frame GroupNorm + proj_in (attention.py:369-373) and BasicTransformerBlock's norm1 + attn1 to_q / to_k /
+    to_v (attention.py:513-516; CrossAttention :154, 177-178) as one kernel at C = 320, against the oracle's own functions."""
+    from lavie_amd import ops
+    from oracle import unet_fp32 as O
+    C, G = 320, 32
+    M = NB * D
+    g = gen(NB * D)
+    x = q16(torch.randn(M, C, generator=g) * 1.3 + 0.4 * torch.randn(NB, 1, C, generator=g).repeat_interleave(D, 0).reshape(M, C))
+    gn_g, gn_b = 1.0 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    wpin = q16(torch.randn(C, C, generator=g) / math.sqrt(C))
+    bpin = torch.randn(C, generator=g) * 0.2
+    ln_g, ln_b = 1.0 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    wqkv = q16(torch.randn(3 * C, C, generator=g) / math.sqrt(C))
+    # reference: GroupNorm over (C / 32, D) per frame (eps 1e-6), 1x1 conv, LayerNorm (eps 1e-5), three bias-free projections
+    xn = F.group_norm(x.reshape(NB, D, C).transpose(1, 2), G, gn_g, gn_b, 1e-6).transpose(1, 2).reshape(M, C)
+    tx_ref = xn @ wpin.t() + bpin
+    qkv_ref = F.layer_norm(tx_ref, (C,), ln_g, ln_b, 1e-5) @ wqkv.t()
+    xd = h16(x)
+    ab = ops.group_norm_affine(xd, f32(gn_g), f32(gn_b), NB, G, 1e-6)
+    img = ops.pack_proj_qkv(h16(wpin), h16(wqkv))
+    tx, qkv = ops.proj_qkv(xd, ab, D, img, f32(bpin), f32(ln_g), f32(ln_b))
+    assert rel_l2(tx, tx_ref) < TOL_OP
+    assert rel_l2(qkv, qkv_ref) < 2 * TOL_OP        # two chained products and two norms: the block-level tolerance of the seams
+    for i in range(3):                              # q, k and v each on their own (a permutation of the row blocks would hide in the whole)
+        assert rel_l2(qkv[:, i * C:(i + 1) * C], qkv_ref[:, i * C:(i + 1) * C]) < 2 * TOL_OP
+    # against the unfused operators of this library on the same inputs: same rounding points up to the LayerNorm fold
+    y = ops.group_norm(xd, f32(gn_g), f32(gn_b), NB, G, 1e-6, False)
+    tx_u = ops.linear(y, h16(wpin), f32(bpin))
+    assert rel_l2(tx, tx_u.float().cpu()) < 3e-4
+    tx2, qkv2 = ops.proj_qkv(xd, ab, D, img, f32(bpin), f32(ln_g), f32(ln_b))
+    assert torch.equal(tx, tx2) and torch.equal(qkv, qkv2)
+
+
+def test_proj_qkv_rejects_unbuilt_width():
+    from lavie_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.pack_proj_qkv(torch.zeros(256, 256, dtype=torch.float16, device="cuda"), torch.zeros(768, 256, dtype=torch.float16, device="cuda"))
