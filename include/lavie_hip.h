@@ -73,6 +73,12 @@ int lavie_temporal_conv_f16(const void* x, int C, const void* Wp, const float* b
                             const void* zero_page, void* stream);
 /* [Cout, Cin, T, 1, 1] (PyTorch Conv3d) -> [Cout][T*Cin] in the implicit GEMM's K order (64-channel slab, tap, channel). */
 int lavie_pack_temporal_conv_f16(const void* w, void* out, int Cout, int Cin, int taps, void* stream);
+/* A GEMM that consumes LayerNorm(A) without the normalised copy (how the engine runs every projection behind a LayerNorm,
+ * BasicTransformerBlock attention.py:513-560): C[m, n] = rstd_m (sum_k A[m, k] Wf[n, k] - mean_m s[n]) + bias[n], with
+ * Wf = W * gamma (fp16), s = row sums of Wf, bias = W beta (+ the layer's bias) prepared by the caller and ln_stats [M, 2] =
+ * (mean, rstd) of the rows of A.  Never splits K. */
+int lavie_linear_lnfold_f16(const void* A, const void* Wf, const float* bias, const float* ln_s, const float* ln_stats, void* C,
+                            int M, int N, int K, void* stream);
 /* GEGLU projection [2*inner, K] (+ bias) -> 16-row value/gate interleave expected by lavie_linear_f16(geglu=1). */
 int lavie_pack_geglu_f16(const void* w, const void* bias_f16, void* w_out, float* bias_out, int N, int K, void* stream);
 

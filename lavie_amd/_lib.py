@@ -32,6 +32,7 @@ class UNetConfigC(C.Structure):
 SIGNATURES = {
     "lavie_last_error": (c_char_p, []),
     "lavie_abi_version": (c_int, []),
+    "lavie_linear_lnfold_f16": (c_int, [c_void_p, c_void_p, c_float_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lavie_linear_f16": (c_int, [c_void_p, c_int, c_void_p, c_float_p, c_float_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lavie_conv3x3_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_float_p,

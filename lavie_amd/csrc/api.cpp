@@ -56,6 +56,20 @@ int lavie_linear_f16(const void* A, int lda, const void* W, const float* bias, c
     return launch_igemm(p, false, geglu ? EPI_GEGLU : EPI_LINEAR, S(stream));
 }
 
+// The consumer side of a folded LayerNorm at operator level (engine.cpp's `LnFold`): C = rstd_m (A W'^T - mean_m s) + bias with
+// W' = W gamma, s = row sums of W', bias = W beta (+ b) prepared by the caller; stats [M, 2] = (mean, rstd) of the rows of A
+int lavie_linear_lnfold_f16(const void* A, const void* Wf, const float* bias, const float* ln_s, const float* ln_stats, void* C,
+                            int M, int N, int K, void* stream) {
+    LAVIE_CHECK(A && Wf && C && ln_s && ln_stats, "linear_lnfold: null tensor");
+    LAVIE_CHECK(K % IGEMM_BK == 0, "linear_lnfold: K=%d must be a multiple of %d", K, IGEMM_BK);
+    IgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = H(A); p.lda = K; p.W = H(Wf); p.ldw = K; p.C = H(C); p.ldc = N; p.bias = bias; p.rows_per_batch = 1;
+    p.M = M; p.N = N; p.nk = K / IGEMM_BK; p.splits = 1;
+    p.ln_s = ln_s; p.ln_stats = ln_stats;
+    return launch_igemm(p, false, EPI_LINEAR, S(stream));
+}
+
 long long lavie_geglu_mlp_image_bytes(int C) { return geglu_mlp_supported(C) ? (long long)geglu_mlp_image_bytes(C) : 0; }
 long long lavie_geglu_mlp_bias_floats(int C) { return geglu_mlp_supported(C) ? (long long)geglu_mlp_bias_floats(C) : 0; }
 int lavie_pack_geglu_mlp_f16(const void* w1, const void* b1_f16, const void* w2, int C, void* img, float* b1img, void* stream) {

@@ -622,6 +622,50 @@ struct FwdCtx {
         if (!c.dry) RUN(expr);    \
     } while (0)
 
+// Development aid (LAVIE_DEBUG_TRACE_HALVES=1): after the named step, wait for the stream and report whether the two batch halves of
+// the rows are bit-equal (meaningful for a forward fed identical halves) — localises an irreproducible kernel
+static bool trace_halves_on() {
+    static const bool on = [] { const char* e = getenv("LAVIE_DEBUG_TRACE_HALVES"); return e && e[0] == '1'; }();
+    return on;
+}
+static int trace_halves(const FwdCtx& c, const char* what, const void* p, size_t rows, size_t row_bytes, int line, int elt) {
+    if (c.dry || !trace_halves_on() || rows % 2 != 0) return 0;
+    LAVIE_HIP(hipStreamSynchronize(c.s));
+    std::vector<unsigned char> h(rows * row_bytes);
+    LAVIE_HIP(hipMemcpy(h.data(), p, h.size(), hipMemcpyDeviceToHost));
+    const size_t half = rows / 2 * row_bytes;
+    size_t bad = 0, first = 0, last = 0, bad_rows = 0, cmin = row_bytes, cmax = 0;
+    for (size_t r = 0; r < rows / 2; ++r) {
+        bool rb = false;
+        for (size_t j = 0; j < row_bytes; ++j) {
+            const size_t i = r * row_bytes + j;
+            if (h[i] != h[half + i]) {
+                if (!bad) first = i;
+                last = i; ++bad; rb = true;
+                if (j < cmin) cmin = j;
+                if (j > cmax) cmax = j;
+            }
+        }
+        bad_rows += rb;
+    }
+    fprintf(stderr, "[halves] line %d %-28s rows %zu x %zu B: %s", line, what, rows, row_bytes, bad ? "DIFFER" : "equal");
+    if (bad) fprintf(stderr, " (%zu bytes in %zu rows, rows %zu .. %zu, col bytes %zu .. %zu)", bad, bad_rows, first / row_bytes, last / row_bytes, cmin, cmax);
+    fprintf(stderr, "\n");
+    if (bad && elt == 2) {          // the first few differing fp16 pairs
+        int shown = 0;
+        for (size_t i = 0; i + 1 < half && shown < 8; i += 2) {
+            if (h[i] == h[half + i] && h[i + 1] == h[half + i + 1]) continue;
+            _Float16 a, b;
+            memcpy(&a, &h[i], 2); memcpy(&b, &h[half + i], 2);
+            fprintf(stderr, "          row %zu col %zu: %.6g vs %.6g (bits %02x%02x %02x%02x)\n", i / row_bytes, (i % row_bytes) / 2, (double)a, (double)b,
+                    h[i + 1], h[i], h[half + i + 1], h[half + i]);
+            ++shown;
+        }
+    }
+    return 0;
+}
+#define TRACE(what, ptr, rows, cols) RUN(trace_halves(c, what, ptr, (size_t)(rows), (size_t)(cols) * sizeof(*(ptr)), __LINE__, (int)sizeof(*(ptr))))
+
 #define WS(var, type, count)                                                                                     \
     type* var = (type*)c.ws->alloc((size_t)(count) * sizeof(type));                                              \
     LAVIE_CHECK(var != nullptr, "workspace exhausted: call lavie_unet_prepare for this shape (needed %zu more B)", \
@@ -813,9 +857,13 @@ int UNet::run_temporal_res(FwdCtx& c, const TemporalResW& r, const half_t* x, ha
     WS(nrm, half_t, M * C);
     WS(h1, half_t, M * C);
     LAUNCH(launch_group_norm(x, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n1.g, r.n1.b, 1e-6f, true, c.gn_ws, nrm, c.s));
+    TRACE("tres.norm1", nrm, M, C);
     RUN(tconv(c, nrm, C, r.w1, r.b1, bias2, ldb2, nullptr, h1, D, C, r.taps1, zero_page_));
+    TRACE("tres.conv1", h1, M, C);
     LAUNCH(launch_group_norm(h1, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n2.g, r.n2.b, 1e-6f, true, c.gn_ws, nrm, c.s));
+    TRACE("tres.norm2", nrm, M, C);
     RUN(tconv(c, nrm, C, r.w2, r.b2, nullptr, 0, x, y, D, C, 3, zero_page_));
+    TRACE("tres.conv2", y, M, C);
     c.ws->release(mark);
     return 0;
 }
@@ -832,6 +880,7 @@ int UNet::run_temporal_module(FwdCtx& c, const TemporalModuleW& m, const half_t*
     RUN(run_temporal_res(c, m.t, x, h1, C, D, tproj + m.t_temb_off, ld_tproj));
     RUN(run_resnet(c, m.s, h1, C, nullptr, 0, tproj + m.s.temb_off, ld_tproj, h2, H, W));
     RUN(linear(c, h2, C, m.shift.w, m.shift.b, C, C, x, y, C, (int)M));
+    TRACE("tmodule.shift", y, M, C);
     c.ws->release(mark);
     return 0;
 }
@@ -854,13 +903,16 @@ int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, cons
     const float eps = r.eps > 0.f ? r.eps : cfg_.norm_eps;
     // norm1: statistics from the producers of x1 / x2 where they left them (cs1 / cs2), else the statistics pass
     LAUNCH(launch_group_norm(x1, C1, x2, C2, c.B, P, G, r.n1.g, r.n1.b, eps, true, c.gn_ws, nrm, c.s, cs1, cs2));
+    TRACE("resnet.norm1", nrm, M, r.cin);
     {
         const half_t* src[1] = {nrm};
         const int srcC[1] = {r.cin};
         RUN(conv3x3(c, src, srcC, 1, nullptr, nullptr, 0, r.w1, 9 * r.cin, r.b1, tproj, ld_tproj, P, nullptr, h1, NI, H, W,
                     r.cout, 1, 0, zero_page_, h1cs, &h1_cs));
     }
+    TRACE("resnet.conv1", h1, M, r.cout);
     LAUNCH(launch_group_norm(h1, r.cout, nullptr, 0, c.B, P, G, r.n2.g, r.n2.b, eps, true, c.gn_ws, n2, c.s, &h1_cs));
+    TRACE("resnet.norm2", n2, M, r.cout);
     {
         const half_t* src[1] = {n2};
         const int srcC[1] = {r.cout};
@@ -886,6 +938,7 @@ int UNet::run_resnet(FwdCtx& c, const ResnetW& r, const half_t* x1, int C1, cons
                     r.cout, 1, 0, zero_page_, y_csbuf, y_cs));
         }
     }
+    TRACE("resnet.conv2", y, M, r.cout);
     c.ws->release(mark);
     return 0;
 }
@@ -960,6 +1013,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     RowStat rsd_pin = rsd;                 // the producer's slot width follows the kernel the planner picks for ITS row count
     rsd_pin.slots = C / igemm_rowstat_cols(Tp, C, C / IGEMM_BK);
     if (!fused_pq) RUN(linear(c, ln, C, t.pin.w, t.pin.b, C, C, nullptr, tx, C, Tp, EPI_LINEAR, nullptr, rowstat ? &rsd_pin : nullptr));
+    if (!shared_prefix) TRACE("block.proj_in", tx, T, C);
 
     if (t.attn1_cross) {
         // VSR only_cross_attention levels: attn1 attends to the text context (vsr/models/attention.py:558-561)
@@ -1001,6 +1055,8 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
             RUN(launch_attention(a, c.s));
         }
     }
+    if (!shared_prefix) TRACE("block.attn1 q(kv)", wide, T, t.attn1_cross ? C : 3 * C);
+    if (!shared_prefix) TRACE("block.attn1", att, T, C);
     if (shared_prefix && !c.dry) {       // the second half of the batch: the same residual stream and attention output so far
         LAVIE_HIP(hipMemcpyAsync(tx + (size_t)Tp * C, tx, (size_t)Tp * C * sizeof(half_t), hipMemcpyDeviceToDevice, c.s));
         LAVIE_HIP(hipMemcpyAsync(att + (size_t)Tp * C, att, (size_t)Tp * C * sizeof(half_t), hipMemcpyDeviceToDevice, c.s));
@@ -1010,6 +1066,7 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
             RUN(launch_cross_block(att, tx, tx, T, c.F * D, C, heads, xb_img_[ti], t.o1.b, t.ln2.g, t.ln2.b, t.o2.b, c.ctx_len, scale, 1e-5f, c.s));
     } else {
     RUN(linear(c, att, C, t.o1.w, t.o1.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, rowstat));
+    TRACE("block.attn1.to_out", tx, T, C);
 
     // text cross-attention (attention.py:524-534); K/V once per video instead of once per frame (364)
     if (fold) {
@@ -1028,8 +1085,10 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         a.o = att; a.ldo = C; a.NBq = NI; a.Lq = D; a.Lk = c.ctx_len; a.heads = heads; a.dh = dh; a.kv_batch_div = c.F; a.scale = scale;
         RUN(launch_attention(a, c.s));
     }
+    TRACE("block.attn2", att, T, C);
     RUN(linear(c, att, C, t.o2.w, t.o2.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, (ff_first ? fused_ff : fused_t) ? nullptr : rowstat));
     }
+    TRACE("block.after text", tx, T, C);
 
     // base block order: temporal -> feed-forward (attention.py:548-560); interpolation block: feed-forward -> temporal
     // (interpolation/models/attention.py:592-604)
@@ -1047,16 +1106,20 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
         if (fold) {
             lf.s = t.s_qkvt;
             RUN(linear(c, tx, C, t.f_qkvt, t.b_qkvt, 3 * C, C, nullptr, wide, 3 * C, T, EPI_LINEAR, &lf));
+            TRACE("temporal.row statistics", lf.stats, T, 2);
         } else {
             LAUNCH(launch_layernorm(tx, t.lnt.g, t.lnt.b, ln, T, C, 1e-5f, c.s));
             RUN(linear(c, ln, C, t.wqkvt, nullptr, 3 * C, C, nullptr, wide, 3 * C, T));
         }
+        TRACE("temporal.qkv before", wide, T, 3 * C);
         if (!c.dry) {
             TemporalParams tp;
             tp.qkv = wide; tp.ld = 3 * C; tp.o = att; tp.ldo = C; tp.B = c.B; tp.F = c.F; tp.D = D; tp.heads = heads; tp.dh = dh;
             tp.bias = cur_tables_->relbias[ti]; tp.rot_cos = cur_tables_->rot_cos; tp.rot_sin = cur_tables_->rot_sin; tp.rot_dim = cfg_.temporal_plain ? 0 : cfg_.rotary_dim; tp.scale = scale;
             RUN(launch_temporal_attention(tp, c.s));
         }
+        TRACE("temporal.qkv", wide, T, 3 * C);
+        TRACE("temporal.attention", att, T, C);
         // its output feeds norm3 only in the base order; in the interpolation order proj_out follows (no LayerNorm).
         // The fused feed-forward kernel takes its LayerNorm statistics from the rows it holds: no partials needed.
         RUN(linear(c, att, C, t.ot.w, t.ot.b, C, C, tx, tx, C, T, EPI_LINEAR, nullptr, (ff_first || fused_ff) ? nullptr : rowstat));
@@ -1085,15 +1148,20 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
     };
     if (ff_first) {
         RUN(feed_forward());
+        TRACE("block.feed-forward", tx, T, C);
         RUN(temporal());
+        TRACE("block.temporal", tx, T, C);
     } else {
         RUN(temporal());
+        TRACE("block.temporal", tx, T, C);
         RUN(feed_forward());
+        TRACE("block.feed-forward", tx, T, C);
     }
 
     // 1x1 proj_out + residual, in place on the block input (attention.py:394-401)
     // (its epilogue leaves the GroupNorm statistics of the block's output for the next resnet / skip consumer: x_cs is rewritten)
     RUN(linear(c, tx, C, t.pout.w, t.pout.b, C, C, x, x, C, T, EPI_LINEAR, nullptr, nullptr, 0, x_csbuf, x_cs));
+    TRACE("block.proj_out", x, T, C);
     c.ws->release(mark);
     return 0;
 }

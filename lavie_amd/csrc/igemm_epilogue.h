@@ -75,10 +75,22 @@ __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 
                 rstd[mt] = p.ln_stats[(size_t)mc * 2 + 1];
             }
         }
+        // One v_fma_f32 + one v_mul_f32 per element, written out: left to the compiler this becomes v_pk_fma_f32 / v_pk_mul_f32 with the
+        // row's mean broadcast by op_sel from whichever register of a pair it landed in, and with three waves per SIMD (the 128 x 64
+        // tile: three workgroups per CU) the LOW half of `v_pk_fma_f32 ... op_sel:[0,1,0]` (scalar taken from the HIGH register of the
+        // pair) was measured reading 0 instead of the mean in lanes 48 - 63, a few launches in ten (round 4: the F = 5 chunk of the VSR
+        // UNet irreproducible; tools/dbg_bn64.py isolates it: the bad elements are exactly those lanes of exactly those instructions,
+        // the value is exactly the one with mean = 0, and two workgroups per CU never show it).  Same arithmetic, same rounding.
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = (acc[nt][mt] - mean[mt] * sv[nt]) * rstd[mt];
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[nt][mt][r];
+                    asm("v_fma_f32 %0, -%1, %2, %0\n\tv_mul_f32 %0, %3, %0" : "+v"(v) : "v"(mean[mt]), "v"(sv[nt][r]), "v"(rstd[mt]));
+                    acc[nt][mt][r] = v;
+                }
     }
     // ---- epilogue: lane holds channels n..n+3 of token m for every (nt, mt) ----
     // Which optional operands exist is decided ONCE (wave-uniform) and the body is instantiated per

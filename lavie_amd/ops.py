@@ -62,6 +62,19 @@ def linear(a, weight, bias=None, residual=None, bias2=None, rows_per_batch=0, ge
     return out
 
 
+def linear_lnfold(a, weight_folded, bias, ln_s, ln_stats):
+    """rstd_m (a @ weight_folded^T - mean_m ln_s) + bias: a projection behind a LayerNorm, the norm folded into the GEMM epilogue
+    (weight_folded = W * gamma, ln_s = its row sums, bias = W beta (+ b), ln_stats [M, 2] = (mean, rstd) of the rows of `a`)."""
+    _chk16(a, weight_folded)
+    _chk32(bias, ln_s, ln_stats)
+    M, K = a.shape
+    N = weight_folded.shape[0]
+    out = torch.empty(M, N, dtype=torch.float16, device=a.device)
+    _lib.check(_lib.load().lavie_linear_lnfold_f16(_p(a), _p(weight_folded), _p(bias), _p(ln_s), _p(ln_stats), _p(out), M, N, K,
+                                                   _stream()), "lavie_linear_lnfold_f16")
+    return out
+
+
 def pack_geglu(weight, bias):
     """GEGLU projection [2*inner, K] -> the value/gate 16-row interleave the geglu epilogue expects."""
     _chk16(weight, bias)

@@ -75,6 +75,28 @@ def test_linear_per_batch_bias(ops):
     assert rel_l2(got, ref) < TOL_OP
 
 
+# the projections behind a LayerNorm (attention.py:513-560) run as GEMMs on the raw rows with the norm folded into the epilogue.
+# Shapes: base level 0 / 1 q|k|v, a ragged one, and the VSR level-1 temporal q|k|v at 3 / 4 / 6 frames of a 64 x 64 latent, where the
+# planner picks the 128 x 64 tile (three workgroups per CU) — round 4 found that launch irreproducible, see DESIGN.md
+@pytest.mark.parametrize("M,N,K", [(2560, 960, 320), (1280, 1920, 640), (1234, 320, 320), (6144, 1536, 512), (8192, 1536, 512),
+                                   (12288, 1536, 512), (6144, 512, 512), (40960, 960, 320)])
+def test_linear_layernorm_folded(ops, M, N, K):
+    g = gen(M + N + K + 1)
+    a = q16(torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g)) + torch.randn(M, 1, generator=g))
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    wf = q16(w * gamma)                                   # what launch_ln_fold prepares at load time
+    s, bf = wf.sum(1), w @ beta + bias
+    stats = torch.stack([a.mean(1), (a.var(1, unbiased=False) + 1e-5).rsqrt()], 1)
+    ref = F.layer_norm(a, (K,), gamma, beta, 1e-5) @ w.t() + bias
+    ad, wd, bd, sd, std = h16(a), h16(wf), f32(bf), f32(s), f32(stats)
+    got = ops.linear_lnfold(ad, wd, bd, sd, std)
+    assert rel_l2(got, ref) < TOL_OP
+    for _ in range(20):                                   # bit-reproducible launch to launch
+        assert torch.equal(ops.linear_lnfold(ad, wd, bd, sd, std), got)
+
+
 @pytest.mark.parametrize("M,C", [(256, 320), (200, 640), (2720, 640), (1600, 1280)])     # the last two: blocked tile order, ragged blocks
 def test_geglu(ops, M, C):
     g = gen(C)
