@@ -397,3 +397,46 @@ def test_host_sanitizer_build_is_clean():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "hostcheck: ok" in r.stdout
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_device_code_has_no_op_sel_modified_packed_fp32():
+    """Round 4 (profiles/r04_packed_fp32_op_sel_fault.txt): the low half of `v_pk_fma_f32 ... op_sel:[0,1,0]` was measured
+    reading 0 in lanes 48 - 63 at three waves per SIMD.  The cure is not to emit such forms (hand-written v_fma_f32 in the GEMM
+    epilogue; three files built without packed FP32).  This walks the gfx950 code objects inside the built library and fails on any
+    packed-FP32 instruction that carries an `op_sel:` modifier, so that a compiler or source change cannot bring one back unseen."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        objdump = shutil.which("llvm-objdump")
+    if objdump is None:
+        pytest.skip("no llvm-objdump")
+    blob = open(_lib.LIB_PATH, "rb").read()
+    packed, bad, objects = 0, [], 0
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob):          # one uncompressed offload bundle per translation unit
+        base = m.start()
+        pos = base + 32
+        for _ in range(struct.unpack_from("<Q", blob, base + 24)[0]):
+            off, size, idlen = struct.unpack_from("<QQQ", blob, pos)
+            ident = blob[pos + 24:pos + 24 + idlen].decode()
+            pos += 24 + idlen
+            if "gfx950" not in ident or size == 0:
+                continue
+            objects += 1
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(blob[base + off:base + off + size])
+                f.flush()
+                text = subprocess.run([objdump, "-d", f.name], capture_output=True, text=True, check=True).stdout
+            kernel = "?"
+            for line in text.splitlines():
+                head = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if head:
+                    kernel = head.group(1)
+                elif re.search(r"\bv_pk_\w+_f32\b", line):
+                    packed += 1
+                    if "op_sel:" in line:
+                        bad.append(f"{kernel}: {line.strip()[:100]}")
+    assert objects >= 10 and packed > 1000, (objects, packed)            # the walk saw the kernels (attention / GEMMs use packed FP32 freely)
+    assert not bad, "op_sel-modified packed FP32 in device code:\n" + "\n".join(bad[:10])
