@@ -822,7 +822,8 @@ static bool conv3x3_takes_patch_kernel(int NI, int H, int W, int Cin, int Cout) 
 
 // (taps,1,1) temporal conv over the frame axis of token rows [(b f d), C] (IgemmParams temporal mode; 128-row kernel).
 static int tconv(FwdCtx& c, const half_t* x, int C, const half_t* W, const float* bias, const float* bias2, int ldb2,
-                 const half_t* R, half_t* y, int D, int Cout, int taps, const half_t* zero) {
+                 const half_t* R, half_t* y, int D, int Cout, int taps, const half_t* zero, float* cs_buf = nullptr,
+                 GnColStat* cs_out = nullptr) {
     IgemmParams p;
     memset(&p, 0, sizeof(p));
     p.W = W; p.ldw = taps * C; p.C = y; p.ldc = Cout; p.bias = bias; p.bias2 = bias2; p.ldb2 = ldb2;
@@ -836,6 +837,7 @@ static int tconv(FwdCtx& c, const half_t* x, int C, const half_t* W, const float
     p.nseg = 1;
     p.nk = taps * sg.nchunks;
     p.splits = igemm_plan_splits_gather(p);
+    colstat_plan(p, true, cs_buf, cs_out);          // (round 4) the GroupNorm behind a temporal conv folds its epilogue's sums too
     const size_t mark = c.ws->mark();
     if (p.splits > 1) {
         p.slab = (float*)c.ws->alloc((size_t)p.splits * p.M * p.N * sizeof(float));
@@ -850,19 +852,24 @@ static int tconv(FwdCtx& c, const half_t* x, int C, const half_t* W, const float
 // span the whole video (5-D input), eps 1e-6; bias2 = the block's rows of the fused time-embedding projection or nullptr
 // (attention.py:350: temb_channels=None).  y may alias x.
 int UNet::run_temporal_res(FwdCtx& c, const TemporalResW& r, const half_t* x, half_t* y, int C, int D, const float* bias2,
-                           int ldb2) {
+                           int ldb2, const GnColStat* x_cs, float* y_csbuf, GnColStat* y_cs) {
     const size_t M = (size_t)c.B * c.F * D;
     const int P = c.F * D;
     const size_t mark = c.ws->mark();
     WS(nrm, half_t, M * C);
     WS(h1, half_t, M * C);
-    LAUNCH(launch_group_norm(x, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n1.g, r.n1.b, 1e-6f, true, c.gn_ws, nrm, c.s));
+    WS(h1cs, float, colstat_floats(M, C));
+    GnColStat h1_cs;
+    // x_cs (may be null / empty): statistics the producer of x left; y_csbuf / y_cs (may be null): where conv2's go.  y may alias x
+    // and y_csbuf the buffer x_cs points into: norm1's fold has read it (stream order) long before conv2's epilogue writes it
+    LAUNCH(launch_group_norm(x, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n1.g, r.n1.b, 1e-6f, true, c.gn_ws, nrm, c.s, x_cs));
     TRACE("tres.norm1", nrm, M, C);
-    RUN(tconv(c, nrm, C, r.w1, r.b1, bias2, ldb2, nullptr, h1, D, C, r.taps1, zero_page_));
+    RUN(tconv(c, nrm, C, r.w1, r.b1, bias2, ldb2, nullptr, h1, D, C, r.taps1, zero_page_, h1cs, &h1_cs));
     TRACE("tres.conv1", h1, M, C);
-    LAUNCH(launch_group_norm(h1, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n2.g, r.n2.b, 1e-6f, true, c.gn_ws, nrm, c.s));
+    LAUNCH(launch_group_norm(h1, C, nullptr, 0, c.B, P, cfg_.norm_groups, r.n2.g, r.n2.b, 1e-6f, true, c.gn_ws, nrm, c.s, &h1_cs));
     TRACE("tres.norm2", nrm, M, C);
-    RUN(tconv(c, nrm, C, r.w2, r.b2, nullptr, 0, x, y, D, C, 3, zero_page_));
+    if (y_cs) *y_cs = GnColStat();
+    RUN(tconv(c, nrm, C, r.w2, r.b2, nullptr, 0, x, y, D, C, 3, zero_page_, y_csbuf, y_cs));
     TRACE("tres.conv2", y, M, C);
     c.ws->release(mark);
     return 0;
@@ -871,15 +878,17 @@ int UNet::run_temporal_res(FwdCtx& c, const TemporalResW& r, const half_t* x, ha
 // TemporalModule3D.forward (vsr/models/temporal_module.py:153-178): y = x + shift_conv(resblocks_3d_s(resblocks_3d_t(x))).
 // y must not alias x when x is still referenced as a skip tensor.
 int UNet::run_temporal_module(FwdCtx& c, const TemporalModuleW& m, const half_t* x, half_t* y, const float* tproj,
-                              int ld_tproj, int H, int W) {
+                              int ld_tproj, int H, int W, const GnColStat* x_cs, float* y_csbuf, GnColStat* y_cs) {
     const int C = m.C, D = H * W;
     const size_t M = (size_t)c.B * c.F * D;
     const size_t mark = c.ws->mark();
     WS(h1, half_t, M * C);
     WS(h2, half_t, M * C);
-    RUN(run_temporal_res(c, m.t, x, h1, C, D, tproj + m.t_temb_off, ld_tproj));
-    RUN(run_resnet(c, m.s, h1, C, nullptr, 0, tproj + m.s.temb_off, ld_tproj, h2, H, W));
-    RUN(linear(c, h2, C, m.shift.w, m.shift.b, C, C, x, y, C, (int)M));
+    WS(h1cs, float, colstat_floats(M, C));
+    GnColStat h1_cs;
+    RUN(run_temporal_res(c, m.t, x, h1, C, D, tproj + m.t_temb_off, ld_tproj, x_cs, h1cs, &h1_cs));
+    RUN(run_resnet(c, m.s, h1, C, nullptr, 0, tproj + m.s.temb_off, ld_tproj, h2, H, W, &h1_cs));
+    RUN(linear(c, h2, C, m.shift.w, m.shift.b, C, C, x, y, C, (int)M, EPI_LINEAR, nullptr, nullptr, 0, y_csbuf, y_cs));
     TRACE("tmodule.shift", y, M, C);
     c.ws->release(mark);
     return 0;
@@ -962,8 +971,10 @@ int UNet::run_transformer(FwdCtx& c, const TransformerW& t, half_t* x, const hal
 
     // VSR: ResnetBlock3DCNN (3,1,1) on the block input, before the residual is taken (vsr/models/attention.py:395-400)
     if (t.tres.present) {
-        RUN(run_temporal_res(c, t.tres, x, x, C, D, nullptr, 0));
-        if (x_cs) *x_cs = GnColStat();         // x rewritten in place by kernels that leave no statistics
+        // in place; conv2's epilogue leaves the new statistics where the old ones were (the per-frame GroupNorm below takes them only
+        // if its frames are whole blocks: the temporal tiles of the halo-patch kernel span a video, GnColStat::span)
+        GnColStat in_cs = x_cs ? *x_cs : GnColStat();
+        RUN(run_temporal_res(c, t.tres, x, x, C, D, nullptr, 0, &in_cs, x_csbuf, x_cs));
     }
     // shared_prefix (set_cfg_shared_input; base block only): both halves of the batch are identical up to the text
     // cross-attention, so GroupNorm, proj_in, the qkv projection and the self-attention run on the first half (NIp frames,
@@ -1305,8 +1316,10 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
         if (tmod) {       // after the downsampler, into a NEW buffer: x itself stays alive as a skip (vsr/models/unet.py:523-533)
             const int ll = l + 1 < L ? l + 1 : l;
             WS(yt, half_t, rows(ll) * C);
-            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[ll], Ws[ll]));
-            x = yt; x_cs = GnColStat();
+            WS(ytcs, float, colstat_floats(rows(ll), C));
+            GnColStat yt_cs;
+            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[ll], Ws[ll], &x_cs, ytcs, &yt_cs));
+            x = yt; x_cs = yt_cs;
         }
     }
     {
@@ -1325,8 +1338,10 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
         x = y1; C = r1.cout; x_cs = y_cs;
         if (tmod) {
             WS(yt, half_t, rows(l) * C);
-            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[l], Ws[l]));
-            x = yt; x_cs = GnColStat();
+            WS(ytcs, float, colstat_floats(rows(l), C));
+            GnColStat yt_cs;
+            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[l], Ws[l], &x_cs, ytcs, &yt_cs));
+            x = yt; x_cs = yt_cs;
         }
     }
     for (int i = 0; i < L; ++i) {
@@ -1352,8 +1367,10 @@ int UNet::run(FwdCtx& c, const half_t* sample, const float* timesteps, const hal
         if (tmod) {       // after the upsampler (vsr/models/unet.py:575-590)
             const int ll = i + 1 < L ? l - 1 : l;
             WS(yt, half_t, rows(ll) * C);
-            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[ll], Ws[ll]));
-            x = yt; x_cs = GnColStat();
+            WS(ytcs, float, colstat_floats(rows(ll), C));
+            GnColStat yt_cs;
+            RUN(run_temporal_module(c, tmods_[mi++], x, yt, tproj, tproj_.N, Hs[ll], Ws[ll], &x_cs, ytcs, &yt_cs));
+            x = yt; x_cs = yt_cs;
         }
     }
     // conv_norm_out + SiLU + conv_out (unet.py:504-506), back to the caller's NCFHW layout
@@ -1385,10 +1402,13 @@ int UNet::prepare(int B, int F, int H, int W, int ctx_len) {
     const bool shared_was = cfg_shared_input_;
     const int mask_was = fused_mask();
     int rc = 0;
-    for (int variant = 0; variant < 4 && rc == 0; ++variant) {
+    // masks: the current one; without the row-resident kernels (bits 0 - 2, 8: their GEMMs and row-statistics buffers appear); and both
+    // again with every workspace-consuming option on (bit 3: the shortcut's own output, 4: the parity form's slabs, 5: statistics buffers)
+    const int masks[4] = {mask_was, mask_was & ~0x107, mask_was | 0x38, (mask_was | 0x38) & ~0x107};
+    for (int variant = 0; variant < 8 && rc == 0; ++variant) {
         if ((variant & 1) && B % 2 != 0) continue;
         cfg_shared_input_ = (variant & 1) != 0;
-        set_fused_mask((variant & 2) ? (mask_was & ~7) : mask_was);
+        set_fused_mask(masks[variant >> 1]);
         DeviceArena plan;
         plan.init_virtual();
         FwdCtx c{nullptr, &plan, true, B, F, ctx_len, nullptr};

@@ -140,9 +140,10 @@ private:
     int pack_resnet(ResnetW* r, hipStream_t s);
     int pack_transformer(TransformerW* t, hipStream_t s);
     int pack_temporal_res(const std::string& prefix, int C, int taps1, TemporalResW* out, hipStream_t s);
-    int run_temporal_res(FwdCtx& c, const TemporalResW& r, const half_t* x, half_t* y, int C, int D, const float* bias2, int ldb2);
+    int run_temporal_res(FwdCtx& c, const TemporalResW& r, const half_t* x, half_t* y, int C, int D, const float* bias2, int ldb2,
+                         const GnColStat* x_cs = nullptr, float* y_csbuf = nullptr, GnColStat* y_cs = nullptr);
     int run_temporal_module(FwdCtx& c, const TemporalModuleW& m, const half_t* x, half_t* y, const float* tproj, int ld_tproj,
-                            int H, int W);
+                            int H, int W, const GnColStat* x_cs = nullptr, float* y_csbuf = nullptr, GnColStat* y_cs = nullptr);
     int pack_sampler(const std::string& prefix, int C, SamplerW* out, hipStream_t s, bool up = false);
     int ensure_tables(int F, hipStream_t s);
 

@@ -280,3 +280,44 @@ def test_vsr_production_shape_properties():
     assert torch.equal(y5, y5b)
     assert rel_l2(net(x, 20, low, encoder_hidden_states=ctx, class_labels=labels).sample, y) > 1e-3
     assert rel_l2(net(x, 500, low, encoder_hidden_states=ctx, class_labels=torch.tensor([300, 300])).sample, y) > 1e-4
+
+
+def test_vsr_groupnorm_statistics_from_producers_verified():
+    """Round 4: in the VSR UNet the GroupNorms behind the temporal (T,1,1) convs, behind `TemporalModule3D`'s shift conv and behind the
+    module's inputs fold the producing kernel's epilogue sums too (temporal-conv tiles of the halo-patch kernel: a block's rows are
+    scattered over ONE video, `GnColStat::span`).  Verify mode (bit 6 of lavie_debug_fused_mask) runs the statistics pass beside every
+    such norm and compares (mean, rstd) per (batch, group) on the host; the forward's result must not depend on the mode.  Production
+    width at a reduced frame size (64 x 64: every level's tiles, split-K reduces at the deep levels) with 8 and 5 frames, and the
+    full 320 x 512 chunk."""
+    from lavie_amd import _lib, spec, weights
+    from lavie_amd.config import VSR_CONFIG
+    from lavie_amd.vsr import UNet3DVSRModel
+    lib = _lib.load()
+    DEF = _lib.FUSED_DEFAULT
+    sd = weights.synth_state_dict(spec.param_shapes(VSR_CONFIG), 0)
+    net = UNet3DVSRModel(init_weights=False, sample_size=128, down_temporal_idx=(0, 1, 2, 3), mid_temporal=True, up_temporal_idx=(0, 1, 2, 3))
+    net.load_state_dict({k: v.half() for k, v in sd.items()})
+    del sd
+    net = net.to("cuda", torch.float16)
+    g = torch.Generator().manual_seed(12)
+    labels = torch.tensor([20, 20])
+    try:
+        for F_, H, W in ((8, 64, 64), (5, 64, 64), (3, 64, 64), (8, 320, 512)):
+            x = torch.randn(2, 4, F_, H, W, generator=g).half().cuda()
+            low = torch.randn(2, 3, F_, H, W, generator=g).half().cuda()
+            ctx = torch.randn(2, 77, 1024, generator=g).half().cuda()
+            outs = {}
+            for mask in (DEF & ~32, DEF):
+                _lib.check(lib.lavie_debug_fused_mask(mask), "lavie_debug_fused_mask")
+                outs[mask] = net(x, 500, low, encoder_hidden_states=ctx, class_labels=labels).sample.clone()
+            assert torch.isfinite(outs[DEF]).all()
+            assert rel_l2(outs[DEF], outs[DEF & ~32]) < 2e-3, (F_, H, W, rel_l2(outs[DEF], outs[DEF & ~32]))
+            n0 = lib.lavie_debug_gn_producer_count()
+            _lib.check(lib.lavie_debug_fused_mask(DEF | 64), "lavie_debug_fused_mask")
+            got = net(x, 500, low, encoder_hidden_states=ctx, class_labels=labels).sample
+            n = lib.lavie_debug_gn_producer_count() - n0
+            assert torch.equal(got, outs[DEF])
+            assert n >= 90, (F_, H, W, n)          # of the 129 GroupNorms of the VSR forward (conv_in's consumers and per-frame norms whose frames are no whole blocks keep the pass)
+            del x, low, ctx, outs, got
+    finally:
+        lib.lavie_debug_fused_mask(DEF)
