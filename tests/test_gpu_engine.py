@@ -802,3 +802,40 @@ def test_pipeline_with_graph_matches_eager(small):
     finally:
         net.enable_graph(False)
     assert torch.equal(eager, graphed)
+
+
+def test_workspace_plan_covers_every_switch_combination(full):
+    """prepare() sizes the workspace from dry runs, the forward may run under other switches (the guided loop turns the
+    shared CFG prefix on AFTER prepare; lavie_debug_fused_mask and the text cache change which GEMMs, split-K slabs and statistics
+    buffers exist).  The plan is the maximum over the switch combinations: after ONE prepare at the production shape, every mask /
+    shared-prefix / cached-context combination must run (no 'workspace exhausted') and agree with the default to the engine's usual
+    kernel-switch tolerance."""
+    import bench
+    from lavie_amd import _lib
+    lib = _lib.load()
+    DEF = _lib.FUSED_DEFAULT
+    net, _ = full
+    pe, ne, lat = bench.synth_inputs(0, "cpu")
+    ctx = torch.cat([ne, pe]).half().cuda()
+    x = torch.cat([lat, lat]).half().cuda()
+    net.cache_context(None)
+    net.set_cfg_shared_input(False)
+    _lib.check(lib.lavie_debug_fused_mask(DEF), "lavie_debug_fused_mask")
+    net._prepared = None
+    net.prepare(2, bench.FRAMES, bench.LAT_H, bench.LAT_W, bench.CTX_LEN)             # once, under the default switches
+    ref = net(x, 500, encoder_hidden_states=ctx).sample.clone()
+    try:
+        for mask in (0, 0x08, 0x10, 0x20, 0x38, DEF | 0x08, DEF & ~0x107, DEF & ~0x20, DEF & ~0x10, 0x1FF & ~0xC0):
+            for shared in (False, True):
+                for cached in (False, True):
+                    _lib.check(lib.lavie_debug_fused_mask(mask), "lavie_debug_fused_mask")
+                    cc = net.cache_context(ctx) if cached else ctx
+                    if not cached:
+                        net.cache_context(None)
+                    net.set_cfg_shared_input(shared)
+                    got = net(x, 500, encoder_hidden_states=cc).sample
+                    assert rel_l2(got, ref) < 3e-3, (hex(mask), shared, cached, rel_l2(got, ref))
+    finally:
+        lib.lavie_debug_fused_mask(DEF)
+        net.set_cfg_shared_input(False)
+        net.cache_context(None)
