@@ -246,7 +246,7 @@ int lavie_debug_rowfuse_variant(int v);   /* tuning: LDS read-ahead depth of the
 /* Test/tuning knob for the implicit-GEMM kernel choice.  Low nibble: 0 automatic, 1 128-row kernel with the widest tile,
  * 3 160x320 ping-pong kernel wherever N % 320 == 0, 4 automatic without the ping-pong
  * kernel, 5 halo-patch conv kernel wherever the conv is eligible, 6 automatic without the halo-patch kernel,
- * 7 persistent ping-pong kernel for every eligible plain GEMM, 8 automatic without it.
+ * 7 persistent ping-pong kernel for every eligible plain GEMM, 8 automatic without it, 9 automatic without the GEGLU GEMMs on it.
  * High nibble: diagnostic ablation build of the forced kernel (results wrong), except 0xC: the halo-patch kernel's ping-pong K loop. */
 int lavie_debug_force_tile(int mode);
 /* Test/tuning knob: force the split-K factor of the implicit GEMM (0 = automatic). */

@@ -505,9 +505,9 @@ static bool ppx_plan_shape(int M, int N, int nk, int epilogue) {
     const int lo = g_force_tile & 0xF;
     if (M % 160 != 0 || nk < 5 || (epilogue == EPI_GEGLU ? N % 256 != 0 : (N % 320 != 0 && N % 256 != 0))) return false;   // = igemm_ppx_eligible's shape part
     if (lo == 7) return true;
-    if (lo == 9) {      // experiment switch (round 4): the automatic rule, plus GEGLU GEMMs with short K loops on the persistent kernel
+    if (lo == 9) {      // A/B switch (round 4): the automatic rule WITHOUT the GEGLU GEMMs on the persistent kernel
         const long tiles9 = (long)(M / 160) * (N / pp_bn(N));
-        return tiles9 >= 256 && nk <= 10;
+        return tiles9 >= 256 && nk <= 10 && epilogue == EPI_LINEAR;
     }
     if (lo != 0 && lo != 6) return false;
     // Measured (tools/check_ppx.py, profiles/r02_ppx_shapes.txt): the persistent kernel wins where the K loop is short and

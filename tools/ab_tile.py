@@ -1,5 +1,7 @@
 """A/B of lavie_debug_force_tile modes inside the full UNet forward at the bench shape (cached context, shared CFG prefix), one
-process, interleaved rounds.  Usage: python tools/ab_tile.py 0 9"""
+process, interleaved rounds.  Usage: python tools/ab_tile.py 0 9 9 0
+(give the modes in A B B A order: the second forward batch of a pair runs ~0.1 ms faster than the first on this pool, which an A B order
+books to B — profiles/r04_ab_persistent_kernel_at_one_tile_per_cu_rejected.txt)"""
 import sys
 
 import torch
