@@ -123,6 +123,23 @@ int main() {
     // operator-level argument checks
     REQUIRE(lavie_linear_f16(nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0, 16, 64, 63, 0, nullptr) != 0);
     REQUIRE(lavie_geglu_mlp_image_bytes(123) == 0);
+    {   // round 4 operators: widths that are not built, null tensors, a frame height that is not a whole number of 16-row tiles
+        REQUIRE(lavie_proj_qkv_image_bytes(256) == 0 && lavie_proj_qkv_image_bytes(320) > 0);
+        std::vector<unsigned short> x(64 * 320), wq(3 * 320 * 320), wp(320 * 320), tx(64 * 320), qkv(64 * 960);
+        std::vector<unsigned short> img((size_t)lavie_proj_qkv_image_bytes(320) / 2);
+        std::vector<float> ab(2 * 320 * 2), v(320, 1.f), ws(1 << 16);
+        REQUIRE(lavie_pack_proj_qkv_f16(wp.data(), wq.data(), 256, img.data(), nullptr) != 0);
+        REQUIRE(lavie_pack_proj_qkv_f16(wp.data(), wq.data(), 320, img.data(), nullptr) == 0);
+        REQUIRE(lavie_group_norm_affine_f16(x.data(), 320, 2, 32, 32, v.data(), v.data(), 1e-6f, ws.data(), ab.data(), nullptr) == 0);
+        REQUIRE(lavie_group_norm_affine_f16(x.data(), 320, 2, 32, 32, v.data(), v.data(), 1e-6f, ws.data(), nullptr, nullptr) != 0);
+        REQUIRE(lavie_proj_qkv_f16(x.data(), ab.data(), 32, img.data(), v.data(), v.data(), v.data(), 1e-5f, tx.data(), qkv.data(), 64, 320, nullptr) == 0);
+        REQUIRE(lavie_proj_qkv_f16(x.data(), ab.data(), 24, img.data(), v.data(), v.data(), v.data(), 1e-5f, tx.data(), qkv.data(), 48, 320, nullptr) != 0);
+        REQUIRE(lavie_proj_qkv_f16(x.data(), nullptr, 32, img.data(), v.data(), v.data(), v.data(), 1e-5f, tx.data(), qkv.data(), 64, 320, nullptr) != 0);
+        std::vector<float> st(64 * 2, 1.f), s3(960, 0.f);
+        REQUIRE(lavie_linear_lnfold_f16(x.data(), wq.data(), v.data(), s3.data(), st.data(), qkv.data(), 64, 960, 320, nullptr) == 0);
+        REQUIRE(lavie_linear_lnfold_f16(x.data(), wq.data(), v.data(), nullptr, st.data(), qkv.data(), 64, 960, 320, nullptr) != 0);
+        REQUIRE(lavie_linear_lnfold_f16(x.data(), wq.data(), v.data(), s3.data(), st.data(), qkv.data(), 64, 960, 300, nullptr) != 0);
+    }
     REQUIRE(lavie_upsample_conv3x3_supported(320, 32, 20, 32) >= 0);
     int buckets[16 * 16];
     REQUIRE(lavie_relpos_buckets(16, 32, 32, buckets) == 0);
