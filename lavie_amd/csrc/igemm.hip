@@ -517,8 +517,10 @@ static bool ppx_plan_shape(int M, int N, int nk, int epilogue) {
     // GEGLU: -10 % in the operator benchmark but +3 % inside the UNet (rocprofv3, profiles/r02_a_kernel_summary.md: its
     // VALU-heavy epilogue stalls both groups once per tile): left to the one-tile kernels.
     // Round 4, re-measured inside the forward (tools/ab_tile.py, profiles/r04_ab_geglu_on_persistent_kernel.txt, same box,
-    // interleaved): with the level-1 GEGLU GEMM (K = 640) on the persistent kernel the forward is 0.1 - 0.2 ms shorter in four
-    // rounds of four (linear class 7.38 -> 7.26 ms): taken (mode 6 keeps the round-3 rule for A/B).
+    // interleaved, A B B A): with the level-1 GEGLU GEMM (K = 640) on the persistent kernel the forward is 0.23 ms shorter (20.18 vs
+    // 20.41 ms) at an unchanged class time — its stores are spread over the launch instead of ending it in one burst: taken (mode 9
+    // runs the automatic rule without it for A/B).  The same run order showed that EXACTLY one tile per CU (level-1 N = 640) still
+    // belongs here and not on the one-tile kernel, although that is 11 % faster in isolation.
     const long tiles = (long)(M / 160) * (N / pp_bn(N));
     if (tiles < 256 || nk > 10) return false;
     return epilogue == EPI_LINEAR || lo == 0;
